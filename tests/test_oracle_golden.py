@@ -1,0 +1,161 @@
+"""
+The CPU oracle (oracle/) against the golden vectors produced by the reference itself
+(tests/golden/make_golden.py).  This is what pins the oracle; the GPU parity tests then compare
+the HIP path with the oracle and with the same fixtures.
+"""
+import numpy as np
+import pytest
+
+
+def test_np_sum_matches_numpy_bitwise(orc):
+    rng = np.random.default_rng(0)
+    for n in [1, 2, 7, 8, 9, 12, 13, 24, 36, 100, 128, 129, 500, 1000]:
+        for _ in range(20):
+            a = rng.standard_normal(n) * 10.0 ** rng.uniform(-3, 3, n)
+            assert orc.np_sum(a) == np.sum(a)
+
+
+def test_global_chroma(orc):
+    rng = np.random.default_rng(1)
+    for nb in (12, 24, 36):
+        c = rng.random((777, nb))
+        expect = np.divide(c.sum(axis=0), np.max(c.sum(axis=0)))  # Serra09.py:28
+        assert np.array_equal(orc.global_chroma(c), expect)
+    with pytest.raises(IOError):
+        orc.global_chroma(rng.random((12, 100)))  # wrong axis, Serra09.py:26-27
+
+
+def test_oti(orc, golden):
+    g = golden("stages")
+    got = [orc.get_oti(a, b) for a, b in zip(g["oti_G1"], g["oti_G2"])]
+    assert np.array_equal(got, g["oti_expected"])
+    # a profile rotated by k has OTI k with respect to itself
+    assert list(g["oti_expected"][:12]) == list(range(12))
+
+
+@pytest.mark.parametrize("c", [0, 1, 2])
+def test_stage_chain(orc, golden, c):
+    g = golden("stages")
+    p = "c%d_" % c
+    X, Y, m, kappa = g[p + "X"], g[p + "Y"], int(g[p + "m"]), float(g[p + "kappa"])
+    oti = orc.get_oti(g[p + "gX"], g[p + "gY"])
+    assert oti == int(g[p + "oti"])
+    csm = orc.get_csm(X, Y, shift=oti)
+    assert np.max(np.abs(csm - g[p + "CSM"])) <= 1e-9   # BLAS order differs; contract is 1e-5
+    # sliding on the reference's own CSM is bit-exact (cumsum order is sequential)
+    assert np.array_equal(orc.sliding_csm(g[p + "CSM"], m), g[p + "S"])
+    S = orc.sliding_csm(csm, m)
+    assert np.max(np.abs(S - g[p + "S"])) <= 1e-9
+    assert np.array_equal(orc.csm_to_binary(S, kappa), g[p + "B1"])
+    B = orc.csm_to_binary_mutual(S, kappa)
+    assert np.array_equal(B, g[p + "B"])
+    M, N = B.shape
+    D = np.zeros(M * N, dtype=np.float32)
+    q = orc.qmax(B.flatten(), D, M, N)
+    assert np.array_equal(D.reshape(M, N), g[p + "Dq"])
+    d = orc.dmax(B.flatten(), D, M, N)                   # reused D, Serra09.py:173-175
+    assert np.array_equal(D.reshape(M, N), g[p + "Dd_reused"])
+    Df = np.zeros(M * N, dtype=np.float32)
+    df = orc.dmax(B.flatten(), Df, M, N)
+    assert np.array_equal(Df.reshape(M, N), g[p + "Dd_fresh"])
+    sc = g[p + "scores"]
+    assert q / (M + N) == sc[0] and d / (M + N) == sc[1] and df / (M + N) == sc[2]
+    for key, mask, ref_score in (("Dsw_mutual", B, sc[3]), ("Dsw_onesided", g[p + "B1"], sc[4])):
+        Dw = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        w = orc.swconstrained(np.ascontiguousarray(mask.flatten()), Dw, M, N)
+        # -0.7 is inexact and the reference is built -Ofast (reassociation): tolerance 1e-5
+        assert np.max(np.abs(Dw.reshape(M + 1, N + 1) - g[p + key])) <= 1e-5
+        assert abs(w - ref_score) <= 1e-5
+
+
+def test_float32_inputs(orc, golden):
+    g = golden("stages")
+    csm = orc.get_csm(g["f32_X"], g["f32_Y"])
+    assert csm.dtype == np.float32
+    assert np.max(np.abs(csm - g["f32_CSM"])) <= 2e-6
+    assert np.array_equal(orc.sliding_csm(g["f32_CSM"], 9), g["f32_S"])
+    assert np.array_equal(orc.csm_to_binary_mutual(g["f32_S"], 0.095), g["f32_B"])
+
+
+def test_kappa_conventions(orc, golden):
+    g = golden("stages")
+    D = g["kap_D"]
+    assert orc.lib().orc_nneighbs(0.25, 50) == 12 and orc.lib().orc_nneighbs(0.11, 50) == 6
+    assert np.array_equal(orc.csm_to_binary(D, 0.25), g["kap_B_frac"])
+    assert np.array_equal(orc.csm_to_binary(D, 0.11), g["kap_B_frac2"])
+    assert np.array_equal(orc.csm_to_binary(D, 7), g["kap_B_int"])
+    assert np.array_equal(orc.csm_to_binary_mutual(D, 7), g["kap_Bm_int"])
+    assert np.array_equal(orc.csm_to_binary_mutual(D, 0.25), g["kap_Bm_frac"])
+    assert np.all(orc.csm_to_binary(D, 0) == 1)          # CRPUtils.py:188-189
+
+
+def test_alignment_cases(orc, golden):
+    g = golden("dp_cases")
+    for k in range(int(g["n_cases"])):
+        p = "k%d_" % k
+        S = g[p + "S"]
+        M, N = S.shape
+        Sf = np.ascontiguousarray(S.flatten())
+        sc = g[p + "scores"]
+        D = np.zeros(M * N, dtype=np.float32)
+        assert orc.qmax(Sf, D, M, N) == sc[0]
+        assert np.array_equal(D.reshape(M, N), g[p + "Dq"])
+        assert orc.dmax(Sf, D, M, N) == sc[1]
+        assert np.array_equal(D.reshape(M, N), g[p + "Dd_reused"])
+        Df = np.zeros(M * N, dtype=np.float32)
+        assert orc.dmax(Sf, Df, M, N) == sc[2]
+        assert np.array_equal(Df.reshape(M, N), g[p + "Dd_fresh"])
+        Dw = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        assert abs(orc.swconstrained(Sf, Dw, M, N) - sc[3]) <= 1e-5
+        assert np.max(np.abs(Dw.reshape(M + 1, N + 1) - g[p + "Dsw"])) <= 1e-5
+    for tag in ("ones", "zeros", "eye"):
+        S = g["ka_" + tag + "_S"]
+        M, N = S.shape
+        Sf = np.ascontiguousarray(S.flatten())
+        sc = g["ka_" + tag + "_scores"]
+        assert orc.qmax(Sf, np.zeros(M * N, np.float32), M, N) == sc[0]
+        assert orc.dmax(Sf, np.zeros(M * N, np.float32), M, N) == sc[1]
+        assert abs(orc.swconstrained(Sf, np.zeros((M + 1) * (N + 1), np.float32), M, N) - sc[2]) <= 1e-5
+
+
+def test_alignment_values_are_half_integers(golden):
+    g = golden("dp_cases")
+    for k in range(int(g["n_cases"])):
+        for key in ("Dq", "Dd_reused", "Dd_fresh"):
+            D = g["k%d_%s" % (k, key)]
+            assert np.array_equal(D * 2, np.round(D * 2))
+
+
+def test_serra09_mini_chain(orc, golden):
+    g = golden("serra09_mini")
+    feats, off, gc, pairs = g["feats"], g["frame_off"], g["gchroma"], g["pairs"]
+    q, d, _ = orc.serra09_pairs(feats, off, gc, pairs, m=9, kappa=0.095, do_oti=True, nthreads=2)
+    assert np.array_equal(q, g["chroma_qmax"])
+    assert np.array_equal(d, g["chroma_dmax"])
+
+
+def test_pairs_1000(orc, golden):
+    g = golden("pairs_1000")
+    feats, off, gc, pairs = g["feats"], g["frame_off"], g["gchroma"], g["pairs"]
+    q, d, _ = orc.serra09_pairs(feats, off, gc, pairs, nthreads=3)
+    assert np.array_equal(q, g["chroma_qmax"])
+    assert np.array_equal(d, g["chroma_dmax"])
+    i, j = pairs[0]
+    X, Y = feats[off[i]:off[i + 1]], feats[off[j]:off[j + 1]]
+    assert orc.get_oti(gc[i], gc[j]) == int(g["oti"][0])
+    S = orc.sliding_csm(orc.get_csm(X, Y, shift=int(g["oti"][0])), 9)
+    B = orc.csm_to_binary_mutual(S, 0.095)
+    assert np.array_equal(np.packbits(B, axis=1), g["B_packed_0"])
+    assert np.max(np.abs(np.diag(S) - g["S_diag_0"])) <= 1e-9
+
+
+def test_evalstats(golden):
+    from oracle.evalstats import get_eval_statistics
+    g = golden("evalstats")
+    for c in range(int(g["n_cases"])):
+        labels = g["e%d_labels" % c]
+        cliques = {}
+        for i, lab in enumerate(labels):
+            cliques.setdefault("clique_%d" % lab, set()).add(i)
+        MR, MRR, MDR, MAP, tops = get_eval_statistics(g["e%d_D" % c], cliques)
+        assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["e%d_stats" % c])
