@@ -1,0 +1,569 @@
+// crp_kernels.hip -- batched stage kernels for the cross-recurrence-plot half of the hot path:
+//   frame norms, OTI (CRPUtils.py:109), cross-similarity (CRPUtils.py:67), sliding window
+//   (CRPUtils.py:24), kNN thresholds + binarisation (CRPUtils.py:169/201).
+// gfx950 (CDNA4) only: wave64, DPP reductions, scalar (SGPR) broadcast of wave-uniform rows.
+#include "common.h"
+#include "wave_ops.h"
+
+#include <math.h>
+
+namespace acoss {
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware block remap: hardware deals consecutive block ids round-robin over the 8 XCDs; this
+// maps them back so that logically consecutive blocks (tiles of one pair, which share the two
+// songs' feature rows) run on one XCD and hit its L2.  Bijective for any grid size.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int xcd_remap(int b, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-frame squared norms (FMA chain in bin order; this order is part of the kernels' contract:
+// every kernel that forms |x|^2+|y|^2-2x.y reads these and therefore agrees bit for bit)
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void frame_norms_kernel(const T *__restrict__ feats, int64_t n_frames,
+                                                          int d, T *__restrict__ norms)
+{
+    const int64_t f = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (f >= n_frames) return;
+    const T *x = feats + f * d;
+    T acc = 0;
+    for (int b = 0; b < d; b++) acc = fma(x[b], x[b], acc);
+    norms[f] = acc;
+}
+
+// ---------------------------------------------------------------------------------------------
+// OTI: one thread per pair.  The 12 products are rounded, then summed in numpy's pairwise order
+// for a contiguous run (eight accumulators combined as a tree, tail sequential), so the scores
+// -- and the first-maximum argmax -- are bit-identical to np.sum(np.roll(C1, s) * C2).
+// ---------------------------------------------------------------------------------------------
+__device__ inline double np_sum_small(const double *a, int n)   // n <= 128
+{
+    if (n < 8) {
+        double acc = 0.0;
+        for (int i = 0; i < n; i++) acc = __dadd_rn(acc, a[i]);
+        return acc;
+    }
+    double r[8];
+    for (int k = 0; k < 8; k++) r[k] = a[k];
+    int i;
+    for (i = 8; i < n - (n % 8); i += 8)
+        for (int k = 0; k < 8; k++) r[k] = __dadd_rn(r[k], a[i + k]);
+    double acc = __dadd_rn(__dadd_rn(__dadd_rn(r[0], r[1]), __dadd_rn(r[2], r[3])),
+                           __dadd_rn(__dadd_rn(r[4], r[5]), __dadd_rn(r[6], r[7])));
+    for (; i < n; i++) acc = __dadd_rn(acc, a[i]);
+    return acc;
+}
+
+__global__ __launch_bounds__(64) void oti_kernel(const double *__restrict__ gchroma, int nbins,
+                                                 acoss_pair_desc *descs, int K)
+{
+    const int p = blockIdx.x * 64 + threadIdx.x;
+    if (p >= K) return;
+    const double *c1 = gchroma + (int64_t)descs[p].song_x * nbins;
+    const double *c2 = gchroma + (int64_t)descs[p].song_y * nbins;
+    double prod[64];
+    int best = 0;
+    double best_score = 0.0;
+    for (int s = 0; s < nbins; s++) {
+        for (int b = 0; b < nbins; b++) {
+            int src = b - s;
+            if (src < 0) src += nbins;
+            prod[b] = __dmul_rn(c1[src], c2[b]);
+        }
+        const double score = np_sum_small(prod, nbins);
+        if (s == 0 || score > best_score) {
+            best_score = score;
+            best = s;
+        }
+    }
+    descs[p].shift = best;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Cross-similarity matrix, materialising (the HBM-roofline-graded kernel).
+//
+// Block = 4 waves, tile = 128 rows x 128 columns.  A lane owns 2 adjacent columns and keeps the
+// two y frames (2 x D values) in VGPRs for the whole tile; a wave walks 32 rows, and the x frame
+// of a row is wave-uniform, so it is fetched with scalar loads and fed to v_fma as an SGPR
+// operand -- no LDS, no per-lane x traffic.  Every store instruction of a wave writes one
+// contiguous 128 x sizeof(T) run of an output row (16 B per lane for float64).
+// Algorithmic traffic: sizeof(T) * (nx*ny + d*(nx+ny)) bytes per pair; the feature re-reads
+// across tiles are served by L2 (tiles of one pair are placed on one XCD).
+// ---------------------------------------------------------------------------------------------
+constexpr int CSM_TM = 128, CSM_TN = 128, CSM_ROWS_PER_WAVE = 32;
+
+template <typename T>
+__device__ inline T clamp_sqrt(T c)
+{
+    c = c < (T)0 ? (T)0 : c;   // CRPUtils.py:83
+    return sqrt(c);
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void csm_kernel(const T *__restrict__ feats, const T *__restrict__ norms,
+                                                  const acoss_pair_desc *__restrict__ descs,
+                                                  int tiles_m, int tiles_n, T *__restrict__ out)
+{
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int i0 = (t / tiles_n) * CSM_TM, j0 = (t % tiles_n) * CSM_TN;
+    if (i0 >= ds.nx || j0 >= ds.ny) return;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int shift = ds.shift;
+
+    // this lane's two y frames
+    const int j = j0 + 2 * lane;
+    const bool ok0 = j < ds.ny, ok1 = j + 1 < ds.ny;
+    T y0[D], y1[D];
+    {
+        const T *yp0 = feats + (ds.y_row0 + (ok0 ? j : 0)) * D;
+        const T *yp1 = feats + (ds.y_row0 + (ok1 ? j + 1 : 0)) * D;
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            y0[b] = yp0[b];
+            y1[b] = yp1[b];
+        }
+    }
+    const T yy0 = norms[ds.y_row0 + (ok0 ? j : 0)];
+    const T yy1 = norms[ds.y_row0 + (ok1 ? j + 1 : 0)];
+
+    // rolled x: X1[f][b] = X[f][(b - shift) mod D]   (np.roll(chroma, oti, axis=0), Serra09.py:167)
+    int rot[D];
+#pragma unroll
+    for (int b = 0; b < D; b++) {
+        int src = b - shift;
+        rot[b] = src < 0 ? src + D : src;
+    }
+
+    T *orow = out + ds.csm_off + (int64_t)j;
+    const bool vec_ok = ((ds.csm_pitch & 1) == 0) && ((ds.csm_off & 1) == 0) && ok1;
+    const int r_begin = i0 + wave * CSM_ROWS_PER_WAVE;
+    const int r_end = min(r_begin + CSM_ROWS_PER_WAVE, ds.nx);
+    for (int i = r_begin; i < r_end; i++) {
+        const T *xp = feats + (ds.x_row0 + i) * D;   // wave-uniform address -> scalar loads
+        const T xx = norms[ds.x_row0 + i];
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            const T xb = xp[rot[b]];
+            a0 = fma(xb, y0[b], a0);
+            a1 = fma(xb, y1[b], a1);
+        }
+        const T c0 = clamp_sqrt(fma((T)-2, a0, xx + yy0));
+        const T c1 = clamp_sqrt(fma((T)-2, a1, xx + yy1));
+        T *dst = orow + (int64_t)i * ds.csm_pitch;
+        if (vec_ok) {
+            if constexpr (sizeof(T) == 8) {
+                *reinterpret_cast<double2 *>(dst) = make_double2(c0, c1);
+            } else {
+                *reinterpret_cast<float2 *>(dst) = make_float2(c0, c1);
+            }
+        } else {
+            if (ok0) dst[0] = c0;
+            if (ok1) dst[1] = c1;
+        }
+    }
+}
+
+// Any feature dimension (d up to a few thousand): one thread per output element, plain loops.
+// Correct-first path for shapes other than the chroma / MFCC ones.
+template <typename T>
+__global__ __launch_bounds__(256) void csm_generic_kernel(const T *__restrict__ feats, const T *__restrict__ norms,
+                                                          int d, const acoss_pair_desc *__restrict__ descs,
+                                                          int tiles_m, int tiles_n, T *__restrict__ out)
+{
+    const int tiles = tiles_m * tiles_n;
+    const int p = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int i = (t / tiles_n) * 16 + (threadIdx.x >> 4), j = (t % tiles_n) * 16 + (threadIdx.x & 15);
+    if (i >= ds.nx || j >= ds.ny) return;
+    const T *x = feats + (ds.x_row0 + i) * d, *y = feats + (ds.y_row0 + j) * d;
+    T acc = 0;
+    for (int b = 0; b < d; b++) {
+        int src = b - ds.shift;
+        if (src < 0) src += d;
+        acc = fma(x[src], y[b], acc);
+    }
+    const T c = fma((T)-2, acc, norms[ds.x_row0 + i] + norms[ds.y_row0 + j]);
+    out[ds.csm_off + (int64_t)i * ds.csm_pitch + j] = clamp_sqrt(c);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Sliding-window (delay embedding) of a materialised CSM: S[i][j] = sqrt(sum_k csm[i+k][j+k]^2).
+// Tile of 32 x 64 outputs; the (32+win-1) x (64+win-1) squared inputs are staged in LDS as
+// float64 (float32 inputs are squared in float32 first, CRPUtils.py:40-41), each thread then
+// sums its diagonals directly (k ascending).  LDS reads are lane-contiguous: conflict-free.
+// ---------------------------------------------------------------------------------------------
+constexpr int SL_TM = 32, SL_TN = 64;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sliding_kernel(const T *__restrict__ csm,
+                                                      const acoss_pair_desc *__restrict__ descs, int win,
+                                                      int tiles_m, int tiles_n, double *__restrict__ S)
+{
+    extern __shared__ double sq[];
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int i0 = (t / tiles_n) * SL_TM, j0 = (t % tiles_n) * SL_TN;
+    if (i0 >= M || j0 >= N) return;
+    const int in_rows = SL_TM + win - 1, in_cols = SL_TN + win - 1;
+    const int ld = in_cols | 1;   // odd pitch
+    const T *src = csm + ds.csm_off;
+    for (int idx = threadIdx.x; idx < in_rows * in_cols; idx += 256) {
+        const int r = idx / in_cols, c = idx % in_cols;
+        const int gi = i0 + r, gj = j0 + c;
+        double v = 0.0;
+        if (gi < ds.nx && gj < ds.ny) {
+            const T x = src[(int64_t)gi * ds.csm_pitch + gj];
+            const T x2 = x * x;
+            v = (double)x2;
+        }
+        sq[r * ld + c] = v;
+    }
+    __syncthreads();
+    const int c = threadIdx.x & 63;
+    const int gj = j0 + c;
+    if (gj >= N) return;
+    for (int r = threadIdx.x >> 6; r < SL_TM; r += 4) {
+        const int gi = i0 + r;
+        if (gi >= M) break;
+        double acc = 0.0;
+        for (int k = 0; k < win; k++) acc += sq[(r + k) * ld + (c + k)];
+        S[ds.crp_off + (int64_t)gi * ds.crp_pitch + gj] = sqrt(acc);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// kNN thresholds.  One wave per row: the row's values sit in registers (EPL per lane), and
+// wave_select_kth() finds the k-th smallest.  The column pass stages 8 adjacent columns of the
+// matrix through LDS (64-byte coalesced reads) and then runs the same in-register selection
+// with one wave per column.
+// thr[] holds the order-preserving key of the threshold value, cut[] the tie cut index.
+// ---------------------------------------------------------------------------------------------
+struct ThreshWork {
+    uint64_t *row_thr;   // [K][max_m]
+    uint64_t *col_thr;   // [K][max_n]
+    int *row_cut;        // [K][max_m]
+    int *col_cut;        // [K][max_n]
+    int max_m, max_n;
+};
+
+__device__ inline void store_uniform_select(int k, int n, uint64_t *thr, int *cut, const SelectResult &r)
+{
+    if ((threadIdx.x & 63) == 0) {
+        *thr = r.thr_key;
+        *cut = r.cut;
+    }
+}
+
+// k <= 0: nothing selected; k >= n: everything.  Encoded so that the mask rule needs no branch.
+__device__ inline bool trivial_select(int k, int n, SelectResult &r)
+{
+    if (k <= 0) { r.thr_key = 0ull; r.cut = -1; return true; }
+    if (k >= n) { r.thr_key = ~0ull; r.cut = 0x7fffffff; return true; }
+    return false;
+}
+
+template <int EPL>
+__global__ __launch_bounds__(256) void select_rows_kernel(const double *__restrict__ S,
+                                                          const acoss_pair_desc *__restrict__ descs,
+                                                          int win, double kappa_k_fixed, int k_mode,
+                                                          ThreshWork w, int rows_blocks)
+{
+    const int p = blockIdx.x / rows_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i = (blockIdx.x % rows_blocks) * 4 + wave;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (i >= M) return;
+    const int lane = threadIdx.x & 63;
+    // neighbour count from the number of columns (CRPUtils.py:190-193); k_mode 0: fraction
+    // (half-even rounding, rint under the default rounding mode), 1: absolute count, 2: all
+    int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)N) : (k_mode == 1 ? (int)kappa_k_fixed : N);
+    SelectResult res;
+    if (!trivial_select(k, N, res)) {
+        const double *row = S + ds.crp_off + (int64_t)i * ds.crp_pitch;
+        uint64_t key[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int j = e * 64 + lane;
+            key[e] = j < N ? f64_key(row[j]) : ~0ull;
+        }
+        res = wave_select_kth<EPL>(key, N, k);
+    }
+    store_uniform_select(k, N, w.row_thr + (int64_t)p * w.max_m + i, w.row_cut + (int64_t)p * w.max_m + i, res);
+}
+
+constexpr int SEL_COLS_PER_BLOCK = 8;
+
+template <int EPL>
+__global__ __launch_bounds__(512) void select_cols_kernel(const double *__restrict__ S,
+                                                          const acoss_pair_desc *__restrict__ descs,
+                                                          int win, double kappa_k_fixed, int k_mode,
+                                                          ThreshWork w, int col_blocks)
+{
+    extern __shared__ double colbuf[];   // [8][ldc]
+    const int p = blockIdx.x / col_blocks;
+    const int j0 = (blockIdx.x % col_blocks) * SEL_COLS_PER_BLOCK;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (j0 >= N) return;
+    constexpr int ldc = EPL * 64 + 2;
+    const double *base = S + ds.crp_off;
+    // 512 threads: 64 rows x 8 columns per sweep, 64-byte segments per row
+    for (int r0 = 0; r0 < M; r0 += 64) {
+        const int r = r0 + (threadIdx.x >> 3), c = threadIdx.x & 7;
+        if (r < M && j0 + c < N) colbuf[c * ldc + r] = base[(int64_t)r * ds.crp_pitch + j0 + c];
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int j = j0 + wave;
+    if (j >= N) return;
+    const int lane = threadIdx.x & 63;
+    int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)M) : (k_mode == 1 ? (int)kappa_k_fixed : M);
+    SelectResult res;
+    if (!trivial_select(k, M, res)) {
+        uint64_t key[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const int i = e * 64 + lane;
+            key[e] = i < M ? f64_key(colbuf[wave * ldc + i]) : ~0ull;
+        }
+        res = wave_select_kth<EPL>(key, M, k);
+    }
+    store_uniform_select(k, M, w.col_thr + (int64_t)p * w.max_n + j, w.col_cut + (int64_t)p * w.max_n + j, res);
+}
+
+// B[i][j] = row rule (and column rule when mutual): 4 columns per thread, one dword store.
+__global__ __launch_bounds__(256) void mask_kernel(const double *__restrict__ S,
+                                                   const acoss_pair_desc *__restrict__ descs, int win,
+                                                   int mutual, ThreshWork w, int blocks_per_pair,
+                                                   uint8_t *__restrict__ B)
+{
+    const int p = blockIdx.x / blocks_per_pair;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int quads = (N + 3) >> 2;
+    const int64_t total = (int64_t)M * quads;
+    for (int64_t q = (int64_t)(blockIdx.x % blocks_per_pair) * 256 + threadIdx.x; q < total;
+         q += (int64_t)blocks_per_pair * 256) {
+        const int i = (int)(q / quads), j = (int)(q % quads) * 4;
+        const uint64_t rt = w.row_thr[(int64_t)p * w.max_m + i];
+        const int rc = w.row_cut[(int64_t)p * w.max_m + i];
+        const double *row = S + ds.crp_off + (int64_t)i * ds.crp_pitch;
+        uint8_t *brow = B + ds.crp_off + (int64_t)i * ds.crp_pitch;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            if (j + c < N) {
+                const uint64_t key = f64_key(row[j + c]);
+                bool on = key < rt || (key == rt && j + c <= rc);
+                if (mutual) {
+                    const uint64_t ct = w.col_thr[(int64_t)p * w.max_n + j + c];
+                    const int cc = w.col_cut[(int64_t)p * w.max_n + j + c];
+                    on = on && (key < ct || (key == ct && i <= cc));
+                }
+                packed |= (on ? 1u : 0u) << (8 * c);
+            }
+        }
+        if (j + 3 < N && (ds.crp_pitch & 3) == 0 && (ds.crp_off & 3) == 0) {
+            *reinterpret_cast<uint32_t *>(brow + j) = packed;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++)
+                if (j + c < N) brow[j + c] = (uint8_t)((packed >> (8 * c)) & 0xff);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host launchers
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+static int launch_norms(const T *feats, int64_t n_frames, int d, T *norms, hipStream_t st)
+{
+    if (!feats || !norms || n_frames < 0 || d < 1) { set_error("frame_norms: bad argument"); return ACOSS_EINVAL; }
+    if (n_frames == 0) return ACOSS_OK;
+    hipLaunchKernelGGL(frame_norms_kernel<T>, dim3((unsigned)ceil_div64(n_frames, 256)), dim3(256), 0, st,
+                       feats, n_frames, d, norms);
+    return launch_check("frame_norms_kernel");
+}
+
+template <typename T>
+static int launch_csm(const T *feats, const T *norms, int d, const acoss_pair_desc *descs, int K,
+                      int max_nx, int max_ny, T *csm, hipStream_t st)
+{
+    if (!feats || !norms || !descs || !csm || K < 0 || d < 1 || max_nx < 1 || max_ny < 1) {
+        set_error("csm_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if (K == 0) return ACOSS_OK;
+    if (d == 12 || d == 13) {
+        const int tm = ceil_div(max_nx, CSM_TM), tn = ceil_div(max_ny, CSM_TN);
+        const int64_t blocks = (int64_t)K * tm * tn;
+        if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
+        if (d == 12)
+            hipLaunchKernelGGL((csm_kernel<T, 12>), dim3((unsigned)blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+        else
+            hipLaunchKernelGGL((csm_kernel<T, 13>), dim3((unsigned)blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+        return launch_check("csm_kernel");
+    }
+    const int tm = ceil_div(max_nx, 16), tn = ceil_div(max_ny, 16);
+    const int64_t blocks = (int64_t)K * tm * tn;
+    if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
+    hipLaunchKernelGGL(csm_generic_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, feats, norms, d, descs, tm, tn, csm);
+    return launch_check("csm_generic_kernel");
+}
+
+template <typename T>
+static int launch_sliding(const T *csm, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                          int max_ny, double *S, hipStream_t st)
+{
+    if (!csm || !descs || !S || K < 0 || win < 1 || win > 64 || max_nx < win || max_ny < win) {
+        set_error("sliding_batch: bad argument (1 <= win <= 64, every song >= win frames)");
+        return ACOSS_EINVAL;
+    }
+    if (K == 0) return ACOSS_OK;
+    const int tm = ceil_div(max_nx - win + 1, SL_TM), tn = ceil_div(max_ny - win + 1, SL_TN);
+    const int64_t blocks = (int64_t)K * tm * tn;
+    if (blocks > 0x7fffffffLL) { set_error("sliding_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
+    const size_t lds = sizeof(double) * (size_t)(SL_TM + win - 1) * (size_t)((SL_TN + win - 1) | 1);
+    hipLaunchKernelGGL(sliding_kernel<T>, dim3((unsigned)blocks), dim3(256), lds, st, csm, descs, win, tm, tn, S);
+    return launch_check("sliding_kernel");
+}
+
+static void kappa_mode(double kappa, double &kv, int &mode)
+{
+    if (kappa == 0.0) { kv = 0.0; mode = 2; }       // CRPUtils.py:188-189
+    else if (kappa < 1.0) { kv = kappa; mode = 0; }  // :190-191
+    else { kv = kappa; mode = 1; }                   // :192-193
+}
+
+}  // namespace acoss
+
+using namespace acoss;
+
+extern "C" {
+
+int acoss_frame_norms_f64(const double *feats, int64_t n_frames, int d, double *norms, void *stream)
+{
+    return launch_norms<double>(feats, n_frames, d, norms, (hipStream_t)stream);
+}
+int acoss_frame_norms_f32(const float *feats, int64_t n_frames, int d, float *norms, void *stream)
+{
+    return launch_norms<float>(feats, n_frames, d, norms, (hipStream_t)stream);
+}
+
+int acoss_oti_batch(const double *gchroma, int nbins, acoss_pair_desc *descs, int K, void *stream)
+{
+    if (!gchroma || !descs || K < 0 || nbins < 1 || nbins > 64) {
+        set_error("oti_batch: bad argument (1 <= nbins <= 64)");
+        return ACOSS_EINVAL;
+    }
+    if (K == 0) return ACOSS_OK;
+    hipLaunchKernelGGL(oti_kernel, dim3(ceil_div(K, 64)), dim3(64), 0, (hipStream_t)stream, gchroma, nbins, descs, K);
+    return launch_check("oti_kernel");
+}
+
+int acoss_csm_batch_f64(const double *feats, const double *norms, int d, const acoss_pair_desc *descs,
+                        int K, int max_nx, int max_ny, double *csm, void *stream)
+{
+    return launch_csm<double>(feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+int acoss_csm_batch_f32(const float *feats, const float *norms, int d, const acoss_pair_desc *descs,
+                        int K, int max_nx, int max_ny, float *csm, void *stream)
+{
+    return launch_csm<float>(feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+
+int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,
+                            int max_nx, int max_ny, double *S, void *stream)
+{
+    return launch_sliding<double>(csm, descs, K, win, max_nx, max_ny, S, (hipStream_t)stream);
+}
+int acoss_sliding_batch_f32(const float *csm, const acoss_pair_desc *descs, int K, int win,
+                            int max_nx, int max_ny, double *S, void *stream)
+{
+    return launch_sliding<float>(csm, descs, K, win, max_nx, max_ny, S, (hipStream_t)stream);
+}
+
+size_t acoss_binarize_work_bytes(int K, int max_nx, int max_ny, int win)
+{
+    const size_t m = (size_t)(max_nx - win + 1 > 0 ? max_nx - win + 1 : 0);
+    const size_t n = (size_t)(max_ny - win + 1 > 0 ? max_ny - win + 1 : 0);
+    return (size_t)(K > 0 ? K : 0) * (m + n) * (sizeof(uint64_t) + sizeof(int)) + 64;
+}
+
+int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                         int max_ny, double kappa, int mutual, uint8_t *B, void *work,
+                         size_t work_bytes, void *stream)
+{
+    if (!S || !descs || !B || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
+        set_error("binarize_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if (K == 0) return ACOSS_OK;
+    if (work_bytes < acoss_binarize_work_bytes(K, max_nx, max_ny, win)) {
+        set_error("binarize_batch: workspace too small");
+        return ACOSS_EINVAL;
+    }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    if (max_m > 2048 || max_n > 2048) {
+        set_error("binarize_batch: matrices larger than 2048 x 2048 are not supported yet");
+        return ACOSS_ENOTSUP;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    ThreshWork w;
+    w.max_m = max_m;
+    w.max_n = max_n;
+    w.row_thr = (uint64_t *)work;
+    w.col_thr = w.row_thr + (size_t)K * max_m;
+    w.row_cut = (int *)(w.col_thr + (size_t)K * max_n);
+    w.col_cut = w.row_cut + (size_t)K * max_m;
+    double kv;
+    int mode;
+    kappa_mode(kappa, kv, mode);
+    {
+        const int rb = ceil_div(max_m, 4);
+        if (max_n <= 1024)
+            hipLaunchKernelGGL(select_rows_kernel<16>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
+        else
+            hipLaunchKernelGGL(select_rows_kernel<32>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
+        int rc = launch_check("select_rows_kernel");
+        if (rc) return rc;
+    }
+    if (mutual) {
+        const int cb = ceil_div(max_n, SEL_COLS_PER_BLOCK);
+        if (max_m <= 1024) {
+            const size_t lds = sizeof(double) * SEL_COLS_PER_BLOCK * (16 * 64 + 2);
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(select_cols_kernel<16>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, S, descs, win, kv, mode, w, cb);
+        } else {
+            const size_t lds = sizeof(double) * SEL_COLS_PER_BLOCK * (32 * 64 + 2);
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(select_cols_kernel<32>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, S, descs, win, kv, mode, w, cb);
+        }
+        int rc = launch_check("select_cols_kernel");
+        if (rc) return rc;
+    }
+    {
+        const int64_t quads = (int64_t)max_m * ((max_n + 3) / 4);
+        const int bpp = (int)(ceil_div64(quads, 256 * 4) < 1 ? 1 : ceil_div64(quads, 256 * 4));
+        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((int64_t)K * bpp)), dim3(256), 0, st, S, descs, win, mutual, w, bpp, B);
+        return launch_check("mask_kernel");
+    }
+}
+
+}  // extern "C"

@@ -1,0 +1,357 @@
+// dp_kernels.hip -- the three alignment recurrences of benchmarking/SequenceAlignment.c as
+// row-sweep kernels for gfx950:  qmax (:113-143), dmax (:147-180), constrained
+// Smith-Waterman (:73-99).
+//
+// Every predecessor of cell (i, j) lies in rows i-1..i-3, so all cells of a row are independent
+// given the previous rows: ONE WAVE owns one matrix and sweeps it row by row; lane l owns CPL
+// adjacent columns whose previous-row values live in VGPRs, the left halo comes from lane l-1
+// through DPP wave_shr, and there are no barriers and no LDS.  The mask row is fetched with one
+// 16-byte load per lane (prefetched a few rows ahead) when the rows are 16-byte aligned.
+// The only consumed output in the reference's callers is the maximum cell; D is written only
+// when the caller passes a buffer (parity / drop-in use).
+#include "common.h"
+#include "wave_ops.h"
+
+namespace acoss {
+
+enum { KIND_QMAX = 0, KIND_DMAX = 1, KIND_SWC = 2 };
+
+struct DpParams {
+    float g_on, g_ext;                  // gammaState
+    float sw_match, sw_mismatch, sw_open, sw_ext;
+    int boundary;                       // dmax: 1 = boundary left behind by qmax on a shared D
+};
+
+__device__ inline float max3f(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
+// byte c of a CPL-byte row segment held in CPL/4 dwords; c in [-4, -1] reads the halo dword
+// (the last dword of lane l-1's segment)
+template <int NW>
+__device__ inline unsigned seg_byte(const unsigned (&w)[NW], unsigned halo, int c)
+{
+    const unsigned word = c < 0 ? halo : w[c >> 2];
+    return (word >> (8 * (c & 3))) & 0xffu;
+}
+
+template <int NW>
+__device__ inline void load_mask_row(const uint8_t *row, int j0, int N, bool aligned, unsigned (&w)[NW])
+{
+    // row == nullptr: rows above the matrix (all zero)
+    if (row == nullptr) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) w[q] = 0;
+        return;
+    }
+    if (aligned && j0 + NW * 4 <= N) {
+#pragma unroll
+        for (int q = 0; q < NW; q += 4) {
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + j0 + 4 * q);
+            w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < NW; q++) {
+            unsigned x = 0;
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                const int j = j0 + 4 * q + b;
+                if (j < N) x |= (unsigned)row[j] << (8 * b);
+            }
+            w[q] = x;
+        }
+    }
+}
+
+// One wave per matrix, CPL columns per lane (cols <= 64*CPL).
+template <int KIND, int CPL>
+__global__ __launch_bounds__(256) void dp_wave_kernel(const uint8_t *__restrict__ S,
+                                                      const acoss_mat_desc *__restrict__ mats, int K,
+                                                      float *__restrict__ D, DpParams prm,
+                                                      float *__restrict__ scores)
+{
+    constexpr int NW = CPL / 4;
+    constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;   // first row/column the recurrence writes
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_mat_desc md = mats[p];
+    const int M = md.rows, N = md.cols;
+    if (M < FIRST + 1 || N < FIRST + 1) {   // SequenceAlignment.c:78-80 / 117-119 / 151-153
+        if (lane == 0) scores[p] = 0.0f;
+        return;
+    }
+    const uint8_t *sbase = S + md.s_off;
+    const bool aligned = ((md.s_pitch & 15) == 0) && ((md.s_off & 15) == 0);
+    // For the Smith-Waterman the D grid is offset by one row and one column (SequenceAlignment.c:77,85)
+    const int dshift = (KIND == KIND_SWC) ? 1 : 0;
+    float *dbase = D ? D + md.d_off + (int64_t)dshift * md.d_pitch + dshift : nullptr;
+    const int j0 = lane * CPL;
+
+    float d1[CPL], d2[CPL], d3[CPL];           // rows i-1, i-2, i-3 of D
+    unsigned s1[NW], s2[NW], s3[NW];           // rows i-1, i-2, i-3 of the mask
+    // ---- initial rows (0 .. FIRST-1)
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { d1[c] = 0.f; d2[c] = 0.f; d3[c] = 0.f; }
+    if (dbase) {
+        // in/out semantics of the reference: untouched cells of D are boundary values
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j = j0 + c;
+            if (j < N) {
+                d1[c] = dbase[(int64_t)(FIRST - 1) * md.d_pitch + j];
+                d2[c] = dbase[(int64_t)(FIRST - 2) * md.d_pitch + j];
+                if (KIND == KIND_DMAX) d3[c] = dbase[j];
+            }
+        }
+    }
+    load_mask_row<NW>(sbase + (int64_t)(FIRST - 1) * md.s_pitch, j0, N, aligned, s1);
+    load_mask_row<NW>(sbase + (int64_t)(FIRST - 2) * md.s_pitch, j0, N, aligned, s2);
+    if (KIND == KIND_DMAX) load_mask_row<NW>(sbase, j0, N, aligned, s3);
+    else load_mask_row<NW>(nullptr, j0, N, aligned, s3);
+    if (KIND == KIND_DMAX && !dbase && prm.boundary) {
+        // qmax leaves D[2][j] = (S[2][j] == 1) for j >= 2 on a zeroed D (Serra09.py:173-175)
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j = j0 + c;
+            d1[c] = (j >= 2 && j < N && seg_byte<NW>(s1, 0, c) == 1u) ? 1.0f : 0.0f;
+        }
+    }
+
+    float best = 0.0f;
+    unsigned s0[NW], snext[NW];
+    load_mask_row<NW>(sbase + (int64_t)FIRST * md.s_pitch, j0, N, aligned, snext);
+    for (int i = FIRST; i < M; i++) {
+#pragma unroll
+        for (int q = 0; q < NW; q++) s0[q] = snext[q];
+        if (i + 1 < M) load_mask_row<NW>(sbase + (int64_t)(i + 1) * md.s_pitch, j0, N, aligned, snext);
+
+        // left halo from lane l-1 (lane 0 gets zeros; its columns < FIRST are never computed)
+        const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
+        const float h1c = lane_shr1(d1[CPL - 3], 0.f);
+        const float h2a = lane_shr1(d2[CPL - 1], 0.f), h3a = lane_shr1(d3[CPL - 1], 0.f);
+        const unsigned hs0 = (unsigned)lane_shr1((int)s0[NW - 1], 0);
+        const unsigned hs1 = (unsigned)lane_shr1((int)s1[NW - 1], 0);
+        const unsigned hs2 = (unsigned)lane_shr1((int)s2[NW - 1], 0);
+        const unsigned hs3 = (unsigned)lane_shr1((int)s3[NW - 1], 0);
+
+        float nd[CPL];
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j = j0 + c;
+            const float p_diag = c >= 1 ? d1[c - 1] : h1a;                       // D[i-1][j-1]
+            const float p_up2 = c >= 1 ? d2[c - 1] : h2a;                        // D[i-2][j-1]
+            const float p_left2 = c >= 2 ? d1[c - 2] : (c == 1 ? h1a : h1b);     // D[i-1][j-2]
+            const unsigned cur = seg_byte<NW>(s0, hs0, c);
+            float v;
+            if (KIND == KIND_QMAX) {
+                if (cur == 1u) {
+                    v = max3f(p_diag, p_up2, p_left2) + 1.0f;
+                } else {
+                    const float g1 = seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                    const float g2 = seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                    const float g3 = seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
+                    v = fmaxf(max3f(p_diag - g1, p_up2 - g2, p_left2 - g3), 0.0f);
+                }
+            } else if (KIND == KIND_DMAX) {
+                const float p_up3 = c >= 1 ? d3[c - 1] : h3a;                                   // D[i-3][j-1]
+                const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));  // D[i-1][j-3]
+                const float s_up1 = (float)seg_byte<NW>(s1, hs1, c);        // S[i-1][j]
+                const float s_up2 = (float)seg_byte<NW>(s2, hs2, c);        // S[i-2][j]
+                const float s_l1 = (float)seg_byte<NW>(s0, hs0, c - 1);     // S[i][j-1]
+                const float s_l2 = (float)seg_byte<NW>(s0, hs0, c - 2);     // S[i][j-2]
+                float c1 = p_diag;
+                float c2 = p_up2 + s_up1;
+                float c3 = p_left2 + s_l1;
+                float c4 = (p_up3 + s_up2) + s_up1;
+                float c5 = (p_left3 + s_l2) + s_l1;
+                if (cur == 1u) {
+                    v = fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5) + 1.0f;
+                } else {
+                    c1 -= seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                    c2 -= seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                    c3 -= seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
+                    c4 -= seg_byte<NW>(s3, hs3, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                    c5 -= seg_byte<NW>(s1, hs1, c - 3) == 1u ? prm.g_on : prm.g_ext;
+                    v = fmaxf(fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5), 0.0f);
+                }
+            } else {   // KIND_SWC, in mask coordinates (a, b) = (i, j), D cell (a+1, b+1)
+                const float ms = cur == 0u ? prm.sw_mismatch : prm.sw_match;
+                const unsigned q1 = seg_byte<NW>(s1, hs1, c - 1);   // S[a-1][b-1]
+                const unsigned q2 = seg_byte<NW>(s2, hs2, c - 1);   // S[a-2][b-1]
+                const unsigned q3 = seg_byte<NW>(s1, hs1, c - 2);   // S[a-1][b-2]
+                const float e1 = cur > 0u ? 0.0f : (q1 > 0u ? prm.sw_open : prm.sw_ext);
+                const float e2 = cur > 0u ? 0.0f : (q2 > 0u ? prm.sw_open : prm.sw_ext);
+                const float e3 = cur > 0u ? 0.0f : (q3 > 0u ? prm.sw_open : prm.sw_ext);
+                v = fmaxf(max3f((p_diag + ms) + e1, (p_up2 + ms) + e2, (p_left2 + ms) + e3), 0.0f);
+            }
+            const bool valid = j >= FIRST && j < N;
+            nd[c] = valid ? v : 0.0f;
+        }
+        // columns the recurrence never writes keep their boundary values
+        if (j0 < FIRST) {
+#pragma unroll
+            for (int c = 0; c < FIRST; c++) {
+                if (dbase) {
+                    nd[c] = dbase[(int64_t)i * md.d_pitch + c];
+                } else if (KIND == KIND_DMAX && prm.boundary && c == 2) {
+                    nd[c] = seg_byte<NW>(s0, 0, 2) == 1u ? 1.0f : 0.0f;   // qmax's D[i][2]
+                }
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j = j0 + c;
+            const bool valid = j >= FIRST && j < N;
+            if (valid) best = fmaxf(best, nd[c]);
+            if (dbase && valid) dbase[(int64_t)i * md.d_pitch + j] = nd[c];
+        }
+#pragma unroll
+        for (int c = 0; c < CPL; c++) { d3[c] = d2[c]; d2[c] = d1[c]; d1[c] = nd[c]; }
+#pragma unroll
+        for (int q = 0; q < NW; q++) { s3[q] = s2[q]; s2[q] = s1[q]; s1[q] = s0[q]; }
+    }
+    // wave max
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if (lane == 0) scores[p] = best;
+}
+
+// Any width: one workgroup per matrix, the last three D rows and mask rows in LDS, one barrier
+// per row.  Slow path for matrices wider than 64*32 columns.
+template <int KIND>
+__global__ __launch_bounds__(256) void dp_block_kernel(const uint8_t *__restrict__ S,
+                                                       const acoss_mat_desc *__restrict__ mats,
+                                                       float *__restrict__ D, DpParams prm,
+                                                       float *__restrict__ scores, int ld)
+{
+    extern __shared__ float lds_f[];
+    constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
+    float *drow = lds_f;                                    // [4][ld]
+    uint8_t *srow = reinterpret_cast<uint8_t *>(drow + 4 * ld);   // [4][ld]
+    __shared__ float red[4];
+    const acoss_mat_desc md = mats[blockIdx.x];
+    const int M = md.rows, N = md.cols;
+    if (M < FIRST + 1 || N < FIRST + 1) {
+        if (threadIdx.x == 0) scores[blockIdx.x] = 0.0f;
+        return;
+    }
+    const uint8_t *sbase = S + md.s_off;
+    const int dshift = (KIND == KIND_SWC) ? 1 : 0;
+    float *dbase = D ? D + md.d_off + (int64_t)dshift * md.d_pitch + dshift : nullptr;
+    for (int r = 0; r < FIRST; r++)
+        for (int j = threadIdx.x; j < N; j += 256) {
+            float dv = dbase ? dbase[(int64_t)r * md.d_pitch + j] : 0.0f;
+            const uint8_t sv = sbase[(int64_t)r * md.s_pitch + j];
+            if (KIND == KIND_DMAX && !dbase && prm.boundary && r == 2) dv = (j >= 2 && sv == 1) ? 1.0f : 0.0f;
+            drow[(r & 3) * ld + j] = dv;
+            srow[(r & 3) * ld + j] = sv;
+        }
+    float best = 0.0f;
+    for (int i = FIRST; i < M; i++) {
+        __syncthreads();
+        const float *e1 = drow + ((i - 1) & 3) * ld, *e2 = drow + ((i - 2) & 3) * ld, *e3 = drow + ((i - 3) & 3) * ld;
+        const uint8_t *t1 = srow + ((i - 1) & 3) * ld, *t2 = srow + ((i - 2) & 3) * ld, *t3 = srow + ((i - 3) & 3) * ld;
+        float *e0 = drow + (i & 3) * ld;
+        uint8_t *t0 = srow + (i & 3) * ld;
+        const uint8_t *grow = sbase + (int64_t)i * md.s_pitch;
+        for (int j = threadIdx.x; j < N; j += 256) t0[j] = grow[j];
+        __syncthreads();
+        for (int j = threadIdx.x; j < N; j += 256) {
+            float v;
+            if (j < FIRST) {
+                v = dbase ? dbase[(int64_t)i * md.d_pitch + j] : 0.0f;
+                if (KIND == KIND_DMAX && !dbase && prm.boundary && j == 2) v = t0[2] == 1 ? 1.0f : 0.0f;
+                e0[j] = v;
+                continue;
+            }
+            const unsigned cur = t0[j];
+            if (KIND == KIND_QMAX) {
+                if (cur == 1u) v = max3f(e1[j - 1], e2[j - 1], e1[j - 2]) + 1.0f;
+                else v = fmaxf(max3f(e1[j - 1] - (t1[j - 1] == 1 ? prm.g_on : prm.g_ext),
+                                     e2[j - 1] - (t2[j - 1] == 1 ? prm.g_on : prm.g_ext),
+                                     e1[j - 2] - (t1[j - 2] == 1 ? prm.g_on : prm.g_ext)), 0.0f);
+            } else if (KIND == KIND_DMAX) {
+                float c1 = e1[j - 1];
+                float c2 = e2[j - 1] + (float)t1[j];
+                float c3 = e1[j - 2] + (float)t0[j - 1];
+                float c4 = (e3[j - 1] + (float)t2[j]) + (float)t1[j];
+                float c5 = (e1[j - 3] + (float)t0[j - 2]) + (float)t0[j - 1];
+                if (cur == 1u) v = fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5) + 1.0f;
+                else {
+                    c1 -= t1[j - 1] == 1 ? prm.g_on : prm.g_ext;
+                    c2 -= t2[j - 1] == 1 ? prm.g_on : prm.g_ext;
+                    c3 -= t1[j - 2] == 1 ? prm.g_on : prm.g_ext;
+                    c4 -= t3[j - 1] == 1 ? prm.g_on : prm.g_ext;
+                    c5 -= t1[j - 3] == 1 ? prm.g_on : prm.g_ext;
+                    v = fmaxf(fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5), 0.0f);
+                }
+            } else {
+                const float ms = cur == 0u ? prm.sw_mismatch : prm.sw_match;
+                const float x1 = cur > 0u ? 0.0f : (t1[j - 1] > 0 ? prm.sw_open : prm.sw_ext);
+                const float x2 = cur > 0u ? 0.0f : (t2[j - 1] > 0 ? prm.sw_open : prm.sw_ext);
+                const float x3 = cur > 0u ? 0.0f : (t1[j - 2] > 0 ? prm.sw_open : prm.sw_ext);
+                v = fmaxf(max3f((e1[j - 1] + ms) + x1, (e2[j - 1] + ms) + x2, (e1[j - 2] + ms) + x3), 0.0f);
+            }
+            e0[j] = v;
+            best = fmaxf(best, v);
+            if (dbase) dbase[(int64_t)i * md.d_pitch + j] = v;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = best;
+    __syncthreads();
+    if (threadIdx.x == 0) scores[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+template <int KIND>
+static int launch_dp(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                     int boundary, const acoss_align_params *params, float *scores, hipStream_t st)
+{
+    if (!S || !mats || !scores || K < 0 || max_cols < 0) { set_error("align batch: bad argument"); return ACOSS_EINVAL; }
+    if (K == 0) return ACOSS_OK;
+    acoss_align_params ap;
+    if (params) ap = *params; else acoss_default_align_params(&ap);
+    DpParams prm{ap.gamma_onset, ap.gamma_extension, ap.sw_match, ap.sw_mismatch, ap.sw_gap_open, ap.sw_gap_ext, boundary};
+    if (max_cols <= 64 * 16) {
+        hipLaunchKernelGGL((dp_wave_kernel<KIND, 16>), dim3(ceil_div(K, 4)), dim3(256), 0, st, S, mats, K, D, prm, scores);
+        return launch_check("dp_wave_kernel<16>");
+    }
+    if (max_cols <= 64 * 32) {
+        hipLaunchKernelGGL((dp_wave_kernel<KIND, 32>), dim3(ceil_div(K, 4)), dim3(256), 0, st, S, mats, K, D, prm, scores);
+        return launch_check("dp_wave_kernel<32>");
+    }
+    const int ld = (max_cols + 3) & ~3;
+    const size_t lds = (size_t)ld * 4 * (sizeof(float) + 1);
+    if (lds > 160 * 1024 - 64) { set_error("align batch: %d columns exceed the LDS-resident limit", max_cols); return ACOSS_ENOTSUP; }
+    ACOSS_HIP(hipFuncSetAttribute((const void *)dp_block_kernel<KIND>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(dp_block_kernel<KIND>, dim3(K), dim3(256), lds, st, S, mats, D, prm, scores, ld);
+    return launch_check("dp_block_kernel");
+}
+
+}  // namespace acoss
+
+using namespace acoss;
+
+extern "C" {
+
+int acoss_qmax_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                     const acoss_align_params *params, float *scores, void *stream)
+{
+    return launch_dp<KIND_QMAX>(S, mats, K, max_cols, D, 0, params, scores, (hipStream_t)stream);
+}
+
+int acoss_dmax_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                     int boundary, const acoss_align_params *params, float *scores, void *stream)
+{
+    return launch_dp<KIND_DMAX>(S, mats, K, max_cols, D, boundary, params, scores, (hipStream_t)stream);
+}
+
+int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                    const acoss_align_params *params, float *scores, void *stream)
+{
+    return launch_dp<KIND_SWC>(S, mats, K, max_cols, D, 0, params, scores, (hipStream_t)stream);
+}
+
+}  // extern "C"

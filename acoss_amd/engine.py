@@ -1,0 +1,235 @@
+"""
+Device-side plumbing between the Python plugin layer and the C ABI (include/acoss_mi355x.h).
+
+PyTorch is used only for what it is good at here: device memory, streams and (in sharding.py)
+torch.distributed.  All arithmetic happens in libacoss_mi355x.so; tensors cross the boundary as
+raw device pointers.
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import MAT_DESC, PAIR_DESC, AcossError, check
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def require_gpu():
+    if not torch.cuda.is_available():
+        raise AcossError("no MI355X visible to PyTorch-ROCm: acoss_amd has no CPU fallback")
+
+
+def to_device_bytes(arr, device):
+    """numpy structured/plain array -> uint8 device tensor holding the same bytes."""
+    raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+    return torch.from_numpy(raw.copy()).to(device)
+
+
+class DeviceCorpus(object):
+    """
+    A set of songs resident in HBM: frames-major concatenated features (total_frames, d), their
+    per-frame squared norms, and (for chroma) the per-song global chroma used by the OTI.
+    Mirrors the per-song dict of Serra09.load_features (Serra09.py:154) for one feature type.
+    """
+
+    def __init__(self, feats, frame_off, gchroma=None, device=None):
+        require_gpu()
+        lib = _lib.load()
+        self.device = torch.device(device if device is not None else "cuda:%d" % torch.cuda.current_device())
+        feats = np.ascontiguousarray(feats)
+        if feats.dtype not in (np.float32, np.float64):
+            feats = feats.astype(np.float64)
+        self.dtype = feats.dtype
+        self.d = int(feats.shape[1])
+        self.frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+        self.n_songs = len(self.frame_off) - 1
+        self.n_frames = int(self.frame_off[-1])
+        assert feats.shape[0] == self.n_frames
+        with torch.cuda.device(self.device):
+            self.feats = torch.from_numpy(feats).to(self.device)
+            self.norms = torch.empty(self.n_frames, dtype=self.feats.dtype, device=self.device)
+            fn = lib.acoss_frame_norms_f64 if self.dtype == np.float64 else lib.acoss_frame_norms_f32
+            check(fn(_ptr(self.feats), self.n_frames, self.d, _ptr(self.norms), _stream()), "frame_norms")
+            self.gchroma = None
+            if gchroma is not None:
+                self.gchroma = torch.from_numpy(np.ascontiguousarray(gchroma, dtype=np.float64)).to(self.device)
+
+    def lengths(self):
+        return np.diff(self.frame_off)
+
+
+class PairBatch(object):
+    """The plan of one launch batch: K pair descriptors on host and device."""
+
+    def __init__(self, frame_off, pairs, win, device, pitch_align=16):
+        lib = _lib.load()
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+        self.K = int(pairs.shape[0])
+        self.win = int(win)
+        self.descs = np.zeros(self.K, dtype=PAIR_DESC)
+        tc, tr = ctypes.c_int64(0), ctypes.c_int64(0)
+        check(lib.acoss_plan_pairs(frame_off.ctypes.data, len(frame_off) - 1, pairs.ctypes.data, self.K,
+                                   self.win, int(pitch_align), self.descs.ctypes.data,
+                                   ctypes.byref(tc), ctypes.byref(tr)), "plan_pairs")
+        self.total_csm, self.total_crp = int(tc.value), int(tr.value)
+        self.max_nx = int(self.descs["nx"].max()) if self.K else 0
+        self.max_ny = int(self.descs["ny"].max()) if self.K else 0
+        self.device = device
+        self.descs_dev = to_device_bytes(self.descs, device)
+
+    @property
+    def M(self):
+        return self.descs["nx"] - self.win + 1
+
+    @property
+    def N(self):
+        return self.descs["ny"] - self.win + 1
+
+    def set_shifts(self, shifts):
+        self.descs["shift"] = np.asarray(shifts, dtype=np.int32)
+        self.descs_dev = to_device_bytes(self.descs, self.device)
+
+    def fetch_shifts(self):
+        host = self.descs_dev.cpu().numpy().view(PAIR_DESC)
+        self.descs["shift"] = host["shift"]
+        return self.descs["shift"].copy()
+
+    def mats(self, with_d=False, sw=False):
+        """acoss_mat_desc array for the alignment kernels over this batch's CRP matrices.
+        Returns (mats numpy, total D elements)."""
+        m = np.zeros(self.K, dtype=MAT_DESC)
+        m["s_off"] = self.descs["crp_off"]
+        m["rows"] = self.M
+        m["cols"] = self.N
+        m["s_pitch"] = self.descs["crp_pitch"]
+        total = 0
+        if with_d:
+            extra = 1 if sw else 0
+            pitch = m["cols"].astype(np.int64) + extra
+            sizes = (m["rows"].astype(np.int64) + extra) * pitch
+            offs = np.zeros(self.K, dtype=np.int64)
+            if self.K:
+                offs[1:] = np.cumsum(sizes)[:-1]
+            m["d_off"] = offs
+            m["d_pitch"] = pitch
+            total = int(sizes.sum())
+        return m, total
+
+
+# ---------------------------------------------------------------------------------------------
+# stage wrappers (device tensors in, device tensors out)
+# ---------------------------------------------------------------------------------------------
+def oti(corpus, batch):
+    """CRPUtils.py:109 for every pair of the batch; fills the descriptors' shift on the device."""
+    if corpus.gchroma is None:
+        raise AcossError("oti: the corpus has no global chroma")
+    check(_lib.load().acoss_oti_batch(_ptr(corpus.gchroma), corpus.gchroma.shape[1], _ptr(batch.descs_dev),
+                                      batch.K, _stream()), "oti_batch")
+
+
+def csm(corpus, batch, out=None):
+    """CRPUtils.py:67 for every pair; returns the flat CSM buffer (dtype of the features)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(max(batch.total_csm, 1), dtype=corpus.feats.dtype, device=corpus.device)
+    fn = lib.acoss_csm_batch_f64 if corpus.dtype == np.float64 else lib.acoss_csm_batch_f32
+    check(fn(_ptr(corpus.feats), _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K,
+             batch.max_nx, batch.max_ny, _ptr(out), _stream()), "csm_batch")
+    return out
+
+
+def sliding(csm_buf, batch, out=None):
+    """CRPUtils.py:24 for every pair; float64 out."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(max(batch.total_crp, 1), dtype=torch.float64, device=csm_buf.device)
+    fn = lib.acoss_sliding_batch_f64 if csm_buf.dtype == torch.float64 else lib.acoss_sliding_batch_f32
+    check(fn(_ptr(csm_buf), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny,
+             _ptr(out), _stream()), "sliding_batch")
+    return out
+
+
+def binarize(S_buf, batch, kappa, mutual=True, out=None, work=None):
+    """CRPUtils.py:169 / :201 for every pair; uint8 out, same layout as S."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.zeros(max(batch.total_crp, 1), dtype=torch.uint8, device=S_buf.device)
+    need = int(lib.acoss_binarize_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=S_buf.device)
+    check(lib.acoss_binarize_batch(_ptr(S_buf), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
+                                   batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out), _ptr(work),
+                                   work.numel(), _stream()), "binarize_batch")
+    return out
+
+
+def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None):
+    """SequenceAlignment.c recurrences over a batch of matrices.  kind in {'qmax','dmax','swc'}.
+    mats: numpy MAT_DESC array.  Returns the float32 score tensor (max cell per matrix)."""
+    lib = _lib.load()
+    K = len(mats)
+    dev = B_buf.device
+    mats_dev = to_device_bytes(mats, dev)
+    scores = torch.empty(max(K, 1), dtype=torch.float32, device=dev)
+    if max_cols is None:
+        max_cols = int(mats["cols"].max()) if K else 0
+    pp = ctypes.byref(params) if params is not None else None
+    if kind == "qmax":
+        rc = lib.acoss_qmax_batch(_ptr(B_buf), _ptr(mats_dev), K, max_cols, _ptr(D), pp, _ptr(scores), _stream())
+    elif kind == "dmax":
+        rc = lib.acoss_dmax_batch(_ptr(B_buf), _ptr(mats_dev), K, max_cols, _ptr(D), int(boundary), pp,
+                                  _ptr(scores), _stream())
+    elif kind == "swc":
+        rc = lib.acoss_swc_batch(_ptr(B_buf), _ptr(mats_dev), K, max_cols, _ptr(D), pp, _ptr(scores), _stream())
+    else:
+        raise ValueError("unknown alignment kind %r" % (kind,))
+    check(rc, kind + "_batch")
+    return scores[:K]
+
+
+# ---------------------------------------------------------------------------------------------
+# the Serra09 chain, staged (every intermediate materialised in HBM)
+# ---------------------------------------------------------------------------------------------
+def serra09_scores_staged(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"),
+                          batch_pairs=None, keep=None):
+    """
+    Serra09.py:166-175 for every pair through the stage kernels: oti -> csm -> sliding ->
+    mutual binarise -> qmax [-> dmax on the boundary qmax leaves behind].
+    Returns {kind: float64 ndarray(K)} of scores already divided by (M+N).
+    keep: optional dict that receives the last batch's device buffers (for tests).
+    """
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    K = pairs.shape[0]
+    out = {k: np.zeros(K) for k in want}
+    if K == 0:
+        return out
+    if batch_pairs is None:
+        lens = corpus.lengths()
+        per_pair = float(lens.max()) ** 2 * (corpus.feats.element_size() + 9)
+        batch_pairs = int(max(1, min(K, (8 << 30) // max(per_pair, 1.0))))
+    for lo in range(0, K, batch_pairs):
+        sel = pairs[lo:lo + batch_pairs]
+        batch = PairBatch(corpus.frame_off, sel, m, corpus.device)
+        if do_oti:
+            oti(corpus, batch)
+        C = csm(corpus, batch)
+        S = sliding(C, batch)
+        B = binarize(S, batch, kappa, mutual=True)
+        mats, _ = batch.mats()
+        denom = (batch.M + batch.N).astype(np.float64)
+        if "qmax" in want:
+            out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats).cpu().numpy().astype(np.float64) / denom
+        if "dmax" in want:
+            out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
+        if keep is not None:
+            keep.update(batch=batch, C=C, S=S, B=B)
+    return out

@@ -1,0 +1,190 @@
+/*
+ * acoss_mi355x.h -- C ABI of libacoss_mi355x.so: the MI355X (gfx950) implementation of acoss's
+ * pairwise cover-song scoring hot path (Serra09: OTI -> cross-similarity -> sliding window ->
+ * mutual kNN cross-recurrence plot -> qmax / dmax / constrained Smith-Waterman).
+ *
+ * Three groups of entry points:
+ *
+ *  (1) The reference's own native interface, same names and signatures, HOST pointers.  These
+ *      are exactly what benchmarking/pySeqAlign.pxd:3-10 binds from
+ *      benchmarking/SequenceAlignment.c (qmax_c :113, dmax_c :147, swalignimpconstrained :73);
+ *      here they run on the GPU (copy in, one kernel, copy out).
+ *
+ *  (2) Batched stage kernels on DEVICE pointers, one per numeric function of
+ *      benchmarking/CRPUtils.py on the path (get_oti :109, get_csm :67, sliding_csm :24,
+ *      csm_to_binary :169, csm_to_binary_mutual :201) and per alignment recurrence.  The
+ *      reference has no FFI for these (they are numpy); they are what a GPU port of
+ *      Serra09.similarity (Serra09.py:158-196) calls instead.
+ *
+ *  (3) The fused per-batch scorer acoss_serra09_scores(): features in, chroma_qmax /
+ *      chroma_dmax scores out, nothing materialised in HBM but bit-packed masks.
+ *
+ * Conventions: every function returns 0 on success or a negative errno-style code
+ * (ACOSS_E*); acoss_last_error() gives the message for the calling thread.  Nothing here
+ * allocates device memory except the group-(1) host-pointer calls; group (2)/(3) work in
+ * caller-provided buffers and are asynchronous on `stream` (a hipStream_t passed as void*,
+ * NULL = the default stream).  No torch types appear in any signature.
+ */
+#ifndef ACOSS_MI355X_H
+#define ACOSS_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ACOSS_OK        0
+#define ACOSS_EINVAL  (-22)   /* bad argument (null pointer, non-positive size, bad dtype) */
+#define ACOSS_ENOMEM  (-12)   /* device allocation failed (host-pointer calls only) */
+#define ACOSS_EIO      (-5)   /* HIP runtime error; see acoss_last_error() */
+#define ACOSS_ENOTSUP (-95)   /* size beyond what the kernels support (see each function) */
+
+#define ACOSS_ABI_VERSION 1
+
+/* One (X, Y) song pair of a batch.  Songs live in one concatenated, frames-major feature
+ * array `feats` (total_frames x d); x_row0 / y_row0 are the first frame of each song.  The
+ * pair's (nx, ny) cross-similarity matrix lives at csm_off (elements, row pitch csm_pitch) of
+ * the CSM buffer and its (nx-win+1, ny-win+1) cross-recurrence matrices at crp_off (elements,
+ * row pitch crp_pitch) of the S / B buffers.  `shift` is the optimal transposition index
+ * applied to X's bins (np.roll(chroma_i, oti, axis=0), Serra09.py:167); acoss_oti_batch fills
+ * it.  acoss_plan_pairs() builds an array of these on the host. */
+typedef struct acoss_pair_desc {
+    int64_t x_row0;
+    int64_t y_row0;
+    int64_t csm_off;
+    int64_t crp_off;
+    int32_t nx;
+    int32_t ny;
+    int32_t csm_pitch;
+    int32_t crp_pitch;
+    int32_t shift;
+    int32_t song_x;     /* indices into gchroma (and the caller's song list) */
+    int32_t song_y;
+    int32_t reserved;
+} acoss_pair_desc;      /* 64 bytes */
+
+/* One binary matrix handed to an alignment kernel: S is (rows, cols) uint8 with row pitch
+ * s_pitch at s_off; D (optional) is float32 with row pitch d_pitch at d_off.  For qmax / dmax
+ * D is (rows, cols); for the constrained Smith-Waterman it is (rows+1, cols+1)
+ * (SequenceAlignment.c:65-69). */
+typedef struct acoss_mat_desc {
+    int64_t s_off;
+    int64_t d_off;
+    int32_t rows;
+    int32_t cols;
+    int32_t s_pitch;
+    int32_t d_pitch;
+} acoss_mat_desc;       /* 32 bytes */
+
+/* Alignment penalties; the defaults are the constants hard-coded in the reference
+ * (SequenceAlignment.c:45-46, 57-58, 105-106). */
+typedef struct acoss_align_params {
+    float gamma_onset;      /* 0.5  qmax/dmax gap after a recurrence point */
+    float gamma_extension;  /* 0.5  qmax/dmax gap otherwise */
+    float sw_match;         /* +1   */
+    float sw_mismatch;      /* -1   */
+    float sw_gap_open;      /* -0.5 */
+    float sw_gap_ext;       /* -0.7 */
+} acoss_align_params;
+
+/* ---------------------------------------------------------------------------------------
+ * library / device
+ * ------------------------------------------------------------------------------------- */
+int         acoss_abi_version(void);
+const char *acoss_last_error(void);
+/* Number of visible HIP devices (<0 on error) and selection of the current one. */
+int         acoss_device_count(void);
+int         acoss_set_device(int device);
+void        acoss_default_align_params(acoss_align_params *p);
+
+/* ---------------------------------------------------------------------------------------
+ * (1) reference native interface -- host pointers, synchronous
+ * ------------------------------------------------------------------------------------- */
+/* SequenceAlignment.c:113  S uint8[M*N] row-major, D float32[M*N] in/out (caller zeroes it),
+ * returns the maximum cell; 0.0 and D untouched when M<3 or N<3.  Errors (HIP failure, size
+ * not supported) are reported as a NaN return value and through acoss_last_error(): the
+ * reference signature has no error channel. */
+float qmax_c(unsigned char *S, float *D, int M, int N);
+/* SequenceAlignment.c:147  same buffers; 0.0 when M<4 or N<4.  D is read as well as written:
+ * calling it on the D that qmax_c just filled reproduces Serra09.py:173-175. */
+float dmax_c(unsigned char *S, float *D, int M, int N);
+/* SequenceAlignment.c:73   S uint8[N*M] (N rows), D float32[(N+1)*(M+1)]; note (N, M) order. */
+float swalignimpconstrained(unsigned char *S, float *D, int N, int M);
+
+/* ---------------------------------------------------------------------------------------
+ * host-side planning helper (pure CPU, no HIP)
+ * ------------------------------------------------------------------------------------- */
+/* Fills descs[K] from frame offsets (frame_off[n_songs+1], in frames) and a pair list
+ * (pairs[K][2] song indices): matrix offsets are packed back to back with row pitches
+ * rounded up to `pitch_align` elements (>=1; 16 makes every mask row 16-byte aligned).
+ * total_csm / total_crp receive the element counts of the CSM and S/B buffers.
+ * Serra09.py:162-172 shapes: CSM (nx, ny), CRP (nx-win+1, ny-win+1).  Returns ACOSS_EINVAL if
+ * a song is shorter than `win`. */
+int acoss_plan_pairs(const int64_t *frame_off, int n_songs, const int32_t *pairs, int K,
+                     int win, int pitch_align, acoss_pair_desc *descs,
+                     int64_t *total_csm, int64_t *total_crp);
+
+/* ---------------------------------------------------------------------------------------
+ * (2) batched stage kernels -- device pointers, asynchronous on `stream`
+ * ------------------------------------------------------------------------------------- */
+/* Per-frame squared norms sum_b x[b]^2 of a (n_frames, d) feature array; the CSM kernels take
+ * them as input (the np.sum(X**2, 1) terms of CRPUtils.py:82). */
+int acoss_frame_norms_f64(const double *feats, int64_t n_frames, int d, double *norms, void *stream);
+int acoss_frame_norms_f32(const float *feats, int64_t n_frames, int d, float *norms, void *stream);
+
+/* CRPUtils.py:109-136 get_oti for every pair: descs[p].shift = argmax_s sum_b
+ * roll(g[song_x], s)[b] * g[song_y][b], first maximum wins; gchroma is (n_songs, nbins)
+ * float64 (Serra09.py:24-28).  nbins <= 64. */
+int acoss_oti_batch(const double *gchroma, int nbins, acoss_pair_desc *descs, int K, void *stream);
+
+/* CRPUtils.py:67-84 get_csm for every pair: csm[csm_off + i*csm_pitch + j] =
+ * sqrt(max(0, |x_i|^2 + |y_j|^2 - 2 x_i.y_j)) with X's bins rotated by descs[p].shift.
+ * Output dtype = input dtype (float64 for crema chroma, float32 for essentia HPCP).
+ * max_nx / max_ny bound the launch grid (>= every nx / ny of the batch).  d <= 64. */
+int acoss_csm_batch_f64(const double *feats, const double *norms, int d,
+                        const acoss_pair_desc *descs, int K, int max_nx, int max_ny,
+                        double *csm, void *stream);
+int acoss_csm_batch_f32(const float *feats, const float *norms, int d,
+                        const acoss_pair_desc *descs, int K, int max_nx, int max_ny,
+                        float *csm, void *stream);
+
+/* CRPUtils.py:24-45 sliding_csm: S[i][j] = sqrt(sum_{k<win} csm[i+k][j+k]^2), always float64
+ * out.  S is written at crp_off with pitch crp_pitch.  1 <= win <= 64. */
+int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,
+                            int max_nx, int max_ny, double *S, void *stream);
+int acoss_sliding_batch_f32(const float *csm, const acoss_pair_desc *descs, int K, int win,
+                            int max_nx, int max_ny, double *S, void *stream);
+
+/* CRPUtils.py:169-199 / 201-219 csm_to_binary(_mutual): B[i][j] = 1 iff S[i][j] is among the
+ * k_row smallest of row i (and, when mutual != 0, among the k_col smallest of column j);
+ * k_row = round_half_even(kappa*cols) for 0<kappa<1, (int)kappa for kappa>=1, everything for
+ * kappa == 0; k_col likewise from the row count.  Ties at the k-th value are resolved
+ * lowest-index first (the reference's tie order is np.argpartition-internal).
+ * `work` must hold acoss_binarize_work_bytes() bytes.  Supports rows, cols <= 2048. */
+size_t acoss_binarize_work_bytes(int K, int max_nx, int max_ny, int win);
+int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win,
+                         int max_nx, int max_ny, double kappa, int mutual, uint8_t *B,
+                         void *work, size_t work_bytes, void *stream);
+
+/* SequenceAlignment.c:113 / :147 / :73 over a batch of matrices.  S and D are the bases the
+ * descs' offsets refer to; D may be NULL (scores only: the reference's callers never read D,
+ * Serra09.py:174-175).  When D is given it is read AND written exactly like the reference's
+ * in-place buffer: cells the recurrence never writes keep their previous contents and act as
+ * boundary values.  scores[K] receives the maximum cell (not yet divided by M+N).
+ * max_cols >= every mats[p].cols selects the kernel variant (one wave per matrix up to 2048
+ * columns, one workgroup per matrix with LDS-resident rows up to ~8000 columns).
+ * dmax `boundary`: 0 = zero boundary (fresh D, ChenFusion.py:66), 1 = the boundary qmax
+ * leaves behind when D is not re-zeroed (Serra09.py:173-175); ignored when D is given. */
+int acoss_qmax_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                     const acoss_align_params *params, float *scores, void *stream);
+int acoss_dmax_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                     int boundary, const acoss_align_params *params, float *scores, void *stream);
+int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
+                    const acoss_align_params *params, float *scores, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ACOSS_MI355X_H */
