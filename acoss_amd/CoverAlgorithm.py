@@ -1,0 +1,370 @@
+"""
+Mirror of the reference's plugin base class (benchmarking/CoverAlgorithm.py:12-418) for the
+MI355X scoring path: same constructor, attributes, overridable hooks and drivers, so a plugin
+written against the reference (`load_features(i)`, `similarity(idxs)`) keeps working, while
+
+  * all_pairwise() hands the pair list to similarity() in large batches (one GPU launch chain
+    per batch) instead of one pair at a time (CoverAlgorithm.py:176-177) or 45 joblib chunks
+    (:169-173); under torch.distributed the pair list is sharded over the ranks and the score
+    vectors are all-gathered once (sharding.py);
+  * getEvalStatistics() returns exactly the reference's numbers but replaces its O(N^2)
+    pure-Python rank loop (:367-390) by array operations;
+  * persistence uses .npz instead of deepdish .h5 (deepdish / h5py / pytables are not available
+    in this environment): feature files, the all-pairs matrix dump and the batch checkpoints.
+    The on-disk field names are the reference's (preprocess/extractors.py:22-54).
+
+Only what the scoring hot path needs is here; the reference's feature extraction is out of scope.
+"""
+import glob
+import os
+import time
+import warnings
+from itertools import chain
+
+import numpy as np
+
+
+def load_feature_file(path):
+    """One song's feature dict from disk.  .npz natively; .h5 only if h5py happens to exist."""
+    if path.endswith(".npz"):
+        with np.load(path, allow_pickle=False) as z:
+            feats = {k: z[k] for k in z.files}
+        if "label" in feats:
+            feats["label"] = str(feats["label"])
+        return feats
+    try:
+        import h5py  # noqa: F401
+    except ImportError:
+        raise IOError("%s: no HDF5 reader (deepdish/h5py) in this environment; convert the "
+                      "feature files to .npz with the same field names" % path)
+    import h5py
+    with h5py.File(path, "r") as f:
+        feats = {k: (f[k][()] if not isinstance(f[k], h5py.Group) else {kk: f[k][kk][()] for kk in f[k]})
+                 for k in f.keys()}
+    if isinstance(feats.get("label"), bytes):
+        feats["label"] = feats["label"].decode()
+    return feats
+
+
+class CoverAlgorithm(object):
+    """
+    Attributes
+    ----------
+    filepaths: list(string)
+        List of paths to all files in the dataset
+    cliques: {string: set}
+        A dictionary of all cover cliques, where the cliques index into filepaths
+    Ds: {string similarity type: ndarray(num files, num files)}
+        A dictionary of pairwise similarity matrices, whose indices index into filepaths
+    """
+
+    def __init__(self, name="Generic", datapath="features_benchmark", shortname="full", cachedir="cache",
+                 cache2dir="cache2", similarity_types=["main"], do_memmaps=True):
+        self.name = name
+        self.shortname = shortname
+        self.cachedir = cachedir
+        self.corpus = None
+        if isinstance(datapath, str):
+            self.filepaths = sorted(glob.glob("%s/*.h5" % datapath))     # CoverAlgorithm.py:41
+            if len(self.filepaths) == 0:
+                self.filepaths = sorted(glob.glob("%s/*.npz" % datapath))
+        else:
+            # an in-memory corpus (acoss_amd.synth.Corpus): synthetic benchmarks and tests
+            self.corpus = datapath
+            self.filepaths = ["<memory>/song_%06d" % i for i in range(self.corpus.n_songs)]
+        self.cliques = {}
+        self.all_feats = {}   # For caching loaded features
+        self.N = len(self.filepaths)
+        self.do_memmaps = do_memmaps
+        self.similarity_types = similarity_types
+        self.cache2dir = None
+        if do_memmaps:
+            if not os.path.isdir(cachedir):
+                os.makedirs(cachedir)
+            self.Ds = {}
+            for s in similarity_types:
+                self.Ds[s] = np.memmap('%s_%s_dmat' % (self.get_cacheprefix(), s), shape=(self.N, self.N),
+                                       mode='w+', dtype='float32')
+        print("Initialized %s algorithm on %i songs in dataset %s" % (name, self.N, shortname))
+
+    def set_cache2dir(self, cache2dir):
+        self.cache2dir = cache2dir
+        if not os.path.exists(cache2dir):
+            os.mkdir(cache2dir)
+
+    def get_cacheprefix(self):
+        """Descriptive file prefix for cached features and distance matrices (CoverAlgorithm.py:59)."""
+        return "%s/%s_%s" % (self.cachedir, self.name, self.shortname)
+
+    def load_features(self, i):
+        """
+        Load the fields of song i and record its cover clique in self.cliques as a side effect
+        (CoverAlgorithm.py:66-90).  In-memory corpora synthesise the dict.
+        """
+        if self.corpus is not None:
+            x = self.corpus.song(i)
+            feats = {"label": self.corpus.labels[i], "hpcp": x, "crema": x}
+        else:
+            feats = load_feature_file(self.filepaths[i])
+        if not feats['label'] in self.cliques:
+            self.cliques[feats['label']] = set([])
+        self.cliques[feats['label']].add(i)
+        return feats
+
+    def get_all_clique_ids(self, verbose=False):
+        """Clique membership of every song, cached in <prefix>_clique_info.txt (CoverAlgorithm.py:92-114)."""
+        filepath = "%s_clique_info.txt" % self.get_cacheprefix()
+        if self.corpus is not None:
+            for i, lab in enumerate(self.corpus.labels):
+                self.cliques.setdefault(lab, set([])).add(i)
+            return
+        if not os.path.exists(filepath):
+            if not os.path.isdir(self.cachedir):
+                os.makedirs(self.cachedir)
+            with open(filepath, "w") as fout:
+                for i in range(len(self.filepaths)):
+                    feats = CoverAlgorithm.load_features(self, i)
+                    if verbose:
+                        print(i)
+                    fout.write("%i,%s\n" % (i, feats['label']))
+        else:
+            with open(filepath) as fin:
+                for line in fin.readlines():
+                    i, label = line.split(",")
+                    label = label.strip()
+                    if label not in self.cliques:
+                        self.cliques[label] = set([])
+                    self.cliques[label].add(int(i))
+
+    def similarity(self, idxs):
+        """
+        Scores for every row (i, j) of idxs, one array per similarity type; also stored in
+        Ds[type][i, j] when do_memmaps.  The base class scores 0 (CoverAlgorithm.py:117-136).
+        """
+        idxs = np.asarray(idxs).reshape(-1, 2)
+        if self.do_memmaps:
+            self.Ds["main"][idxs[:, 0], idxs[:, 1]] = 0.0
+        return {"main": np.zeros(idxs.shape[0])}
+
+    # --------------------------------------------------------------------------------------
+    def _pair_list(self, symmetric):
+        n = len(self.filepaths)
+        if symmetric:
+            i, j = np.triu_indices(n, k=1)                       # itertools.combinations order (:166)
+        else:
+            i, j = np.nonzero(~np.eye(n, dtype=bool))            # itertools.permutations order (:168)
+        return np.stack([i, j], axis=1).astype(np.int64)
+
+    def all_pairwise(self, parallel=0, n_cores=12, symmetric=False, precomputed=False, batch_pairs=4096):
+        """
+        All pairwise comparisons (CoverAlgorithm.py:138-184).  `parallel` / `n_cores` are accepted
+        for call compatibility; the parallelism here is the GPU batch (and, when
+        torch.distributed is initialised, one process per GPU over a sharded pair list).
+        """
+        tic = time.time()
+        dump = "%s_Ds.npz" % self.get_cacheprefix()
+        if precomputed:
+            with np.load(dump) as z:
+                self.Ds = {k: z[k] for k in z.files}
+            self.get_all_clique_ids()
+        else:
+            all_pairs = self._pair_list(symmetric)
+            rank, world, dist = 0, 1, None
+            try:
+                import torch.distributed as dist
+                if dist.is_available() and dist.is_initialized():
+                    rank, world = dist.get_rank(), dist.get_world_size()
+            except ImportError:
+                dist = None
+            mine = np.arange(len(all_pairs))
+            if world > 1:
+                from . import sharding
+                mine = sharding.shard_indices(self._pair_costs(all_pairs), world, rank)
+            local = {s: np.zeros(len(mine)) for s in self.similarity_types}
+            memmaps, self.do_memmaps = self.do_memmaps, False     # scatter once at the end instead
+            try:
+                for lo in range(0, len(mine), batch_pairs):
+                    res = self.similarity(all_pairs[mine[lo:lo + batch_pairs]])
+                    for s in self.similarity_types:
+                        local[s][lo:lo + batch_pairs] = res[s]
+            finally:
+                self.do_memmaps = memmaps
+            if not hasattr(self, "Ds"):
+                self.Ds = {s: np.zeros((self.N, self.N), dtype=np.float32) for s in self.similarity_types}
+            for s in self.similarity_types:
+                full = local[s]
+                if world > 1:
+                    import torch
+                    from . import sharding
+                    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+                    full = sharding.gather_scores(torch.from_numpy(local[s]).to(dev), mine, len(all_pairs)).cpu().numpy()
+                self.Ds[s][all_pairs[:, 0], all_pairs[:, 1]] = full
+            self.get_all_clique_ids()
+            if symmetric:
+                for similarity_type in self.Ds:
+                    self.Ds[similarity_type] += self.Ds[similarity_type].T     # :180-182
+            if rank == 0:
+                np.savez(dump, **{k: np.asarray(v) for k, v in self.Ds.items()})
+        print("Elapsed Time All Pairwise: %.3g" % (time.time() - tic))
+
+    def _pair_costs(self, pairs):
+        return np.ones(len(pairs))
+
+    def do_batch_features(self, n_batches, idx):
+        """Precompute (and cache) the features of one slice of the dataset (CoverAlgorithm.py:186-201)."""
+        N = len(self.filepaths)
+        w = int(np.ceil(N / n_batches))
+        for i in np.arange(w) + idx * w:
+            if i < N:
+                self.load_features(i)
+
+    def do_batch_subbatch(self, w, idx, wsub, isub, jsub):
+        """
+        One wsub x wsub sub-block of block `idx` of the lower-triangular w x w block grid, pairs
+        with row >= col, the diagonal included (CoverAlgorithm.py:203-247).
+        """
+        N = len(self.filepaths)
+        res = int(N / w)
+        I, J = np.meshgrid(np.arange(res), np.arange(res))
+        I, J = I.flatten(), J.flatten()
+        I, J = I[I >= J], J[I >= J]
+        i, j = I[idx], J[idx]
+        pixi = np.arange(w)[isub * wsub:(isub + 1) * wsub]
+        pixj = np.arange(w)[jsub * wsub:(jsub + 1) * wsub]
+        I, J = np.meshgrid(pixi, pixj)
+        idxs = np.array([I.flatten() + i * w, J.flatten() + j * w]).T
+        idxs = idxs[idxs[:, 0] < N, :]
+        idxs = idxs[idxs[:, 1] < N, :]
+        idxs = idxs[idxs[:, 0] >= idxs[:, 1], :]
+        similarities = self.similarity(idxs)
+        similarities['idxs'] = idxs
+        return similarities
+
+    def do_batch(self, w, idx, wsub=-1):
+        """
+        Compute and checkpoint block `idx` sub-block by sub-block, resuming from
+        <prefix>_<idx>.npz if it exists (CoverAlgorithm.py:249-295).
+        """
+        similarities = {}
+        blocks_completed = {}
+        fout = "{}_{}.npz".format(self.get_cacheprefix(), idx)
+        if os.path.exists(fout):
+            try:
+                with np.load(fout) as z:
+                    similarities = {k[4:]: z[k] for k in z.files if k.startswith("sim_")}
+                    blocks_completed = {(int(a), int(b)): True for a, b in z["blocks_completed"]}
+            except Exception:
+                print("Error loading", fout, ": recomputing")
+                similarities, blocks_completed = {}, {}
+        if wsub == -1:
+            wsub = w
+        k = int(w / wsub)
+        col_range = list(range(k))
+        for i in range(k):
+            for j in col_range:
+                if not (i, j) in blocks_completed:
+                    tic = time.time()
+                    self.all_feats = {}   # :282 drop cached features between sub-blocks
+                    s = self.do_batch_subbatch(w, idx, wsub, i, j)
+                    if len(similarities) == 0:
+                        similarities = s
+                    else:
+                        for key in s:
+                            similarities[key] = np.concatenate((similarities[key], s[key]))
+                    blocks_completed[(i, j)] = True
+                    if not os.path.isdir(self.cachedir):
+                        os.makedirs(self.cachedir)
+                    np.savez(fout, blocks_completed=np.array(sorted(blocks_completed), dtype=np.int64).reshape(-1, 2),
+                             **{"sim_" + key: val for key, val in similarities.items()})
+                    print("Elapsed Time Sub-Batch %i_%i_%i: %.3g" % (idx, i, j, time.time() - tic), flush=True)
+            col_range = list(reversed(col_range))   # zig-zag (:294-295)
+        return similarities
+
+    def load_batches(self, fileprefix):
+        """Scatter-add every checkpointed block into Ds, both triangles (CoverAlgorithm.py:297-317)."""
+        files = glob.glob("{}*.npz".format(fileprefix))
+        for key in self.Ds.keys():
+            self.Ds[key] = np.zeros_like(self.Ds[key])
+        for f in files:
+            with np.load(f) as z:
+                if "sim_idxs" not in z.files:
+                    continue
+                idxs = z["sim_idxs"]
+                I, J = idxs[:, 0], idxs[:, 1]
+                for key in self.Ds.keys():
+                    self.Ds[key][I, J] += z["sim_" + key]
+                    self.Ds[key][J, I] += z["sim_" + key]
+        self.get_all_clique_ids()
+
+    def cleanup_memmap(self):
+        """Remove the memmap files behind Ds (the reference's rmtree on a file never succeeds, :319-328)."""
+        for s in list(getattr(self, "Ds", {})):
+            path = '%s_%s_dmat' % (self.get_cacheprefix(), s)
+            try:
+                if os.path.exists(path):
+                    os.remove(path)
+            except OSError:
+                print('Could not clean-up automatically.')
+
+    # --------------------------------------------------------------------------------------
+    def getEvalStatistics(self, similarity_type, topsidx=[1, 10, 100, 1000], verbose=True, write_csv=True):
+        """
+        MR, MRR, MDR, MAP and Top-X of one similarity type -- the same numbers as
+        CoverAlgorithm.py:330-418 (same permutation, same argsort calls and therefore the same
+        tie-breaking), with the per-row rank loop (:367-390) done on arrays.
+        """
+        D = np.array(self.Ds[similarity_type], dtype=np.float32)
+        N = D.shape[0]
+        cliques = [list(self.cliques[s]) for s in self.cliques]
+        Ks = np.array([len(c) for c in cliques])
+        order = np.argsort(-Ks)                                   # :349 (same call, same tie order)
+        Ks = Ks[order]
+        cliques = [cliques[i] for i in order]
+        perm = np.array(list(chain(*cliques)), dtype=int)
+        D = D[perm, :]
+        D = D[:, perm]
+        np.fill_diagonal(D, -np.inf)
+        idx = np.argsort(-D, 1)                                   # :362
+        # rank (1-based position in its row's ordering) of every column
+        pos = np.empty_like(idx)
+        pos[np.arange(N)[:, None], idx] = np.arange(1, N + 1)[None, :]
+        ranks = np.nan * np.ones(N)
+        AllMap = np.nan * np.ones(N)
+        starts = np.concatenate([[0], np.cumsum(Ks)[:-1]])
+        for start, K in zip(starts, Ks):
+            if K < 2:
+                break                                             # :372-375 cliques are sorted by size
+            block = np.sort(pos[start:start + K, start:start + K], axis=1)[:, :-1]   # drop the last = self (:381)
+            ranks[start:start + K] = block[:, 0]                  # :386
+            j = np.arange(1, K, dtype=np.float64)[None, :]
+            AllMap[start:start + K] = np.mean(j / block.astype(np.float64), axis=1)    # :388-390
+        if np.all(np.isnan(AllMap)):
+            warnings.warn("Recalling 0 songs: no clique with at least 2 songs")
+        MAP = np.nanmean(AllMap)
+        ranks = ranks[np.isnan(ranks) == 0]
+        MR = np.mean(ranks)
+        MRR = 1.0 / N * (np.sum(1.0 / ranks))                     # :395 (divides by ALL songs)
+        MDR = np.median(ranks)
+        if verbose:
+            print("%s %s STATS\n-------------------------\nMR = %.3g\nMRR = %.3g\nMDR = %.3g\nMAP = %.3g"
+                  % (self.name, similarity_type, MR, MRR, MDR, MAP))
+        tops = np.zeros(len(topsidx))
+        for i in range(len(tops)):
+            tops[i] = np.sum(ranks <= topsidx[i])
+            if verbose:
+                print("Top-%i: %i" % (topsidx[i], tops[i]))
+        if write_csv:
+            resultsfile = "results_%s.csv" % self.shortname       # :404-417, same columns
+            if not os.path.exists(resultsfile):
+                with open(resultsfile, "w") as fout:
+                    fout.write("name, MR, MRR, MDR, MAP")
+                    for t in topsidx:
+                        fout.write(",Top-%i" % t)
+                    fout.write("\n")
+            with open(resultsfile, "a") as fout:
+                fout.write("%s_%s," % (self.name, similarity_type))
+                fout.write("%.3g, %.3g, %.3g, %.3g" % (MR, MRR, MDR, MAP))
+                for t in tops:
+                    fout.write(", %.3g" % t)
+                fout.write("\n")
+        return (MR, MRR, MDR, MAP, tops)

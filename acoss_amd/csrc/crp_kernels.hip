@@ -104,7 +104,31 @@ __device__ inline T clamp_sqrt(T c)
     return sqrt(c);
 }
 
-template <typename T, int D>
+// sqrt(max(c, 0)) for the CSM epilogue.  float64: v_rsq_f64 seed, one Goldschmidt step and two
+// Newton corrections (the sequence the compiler's own sqrt uses, correctly rounded), but without
+// the per-element exponent rescaling and class tests: zero flows through the iteration exactly
+// (0 * finite seed), and the only inputs the fast form cannot take -- positive values below
+// 2^-900 -- are sent to the library sqrt by a wave-uniform branch that is never taken on real
+// features.
+__device__ inline double csm_sqrt(double c)
+{
+    c = fmax(c, 0.0);
+    const double tiny = 0x1.0p-900;
+    if (__builtin_expect(__any(c > 0.0 && c < tiny), 0)) return sqrt(c);
+    const double y = __builtin_amdgcn_rsq(fmax(c, tiny));
+    double g = c * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, c), h, g);
+    g = fma(fma(-g, g, c), h, g);
+    return g;
+}
+__device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
+
+// MODE (development probes, product = 0): 1 = stores only (no arithmetic), 2 = arithmetic only (store
+// suppressed), 3 = assume shift == 0 (contiguous scalar loads of the x frame)
+template <typename T, int D, int MODE = 0>
 __global__ __launch_bounds__(256) void csm_kernel(const T *__restrict__ feats, const T *__restrict__ norms,
                                                   const acoss_pair_desc *__restrict__ descs,
                                                   int tiles_m, int tiles_n, T *__restrict__ out)
@@ -118,7 +142,7 @@ __global__ __launch_bounds__(256) void csm_kernel(const T *__restrict__ feats, c
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int shift = ds.shift;
+    const int shift = MODE == 3 ? 0 : ds.shift;
 
     // this lane's two y frames
     const int j = j0 + 2 * lane;
@@ -145,29 +169,52 @@ __global__ __launch_bounds__(256) void csm_kernel(const T *__restrict__ feats, c
     }
 
     T *orow = out + ds.csm_off + (int64_t)j;
-    const bool vec_ok = ((ds.csm_pitch & 1) == 0) && ((ds.csm_off & 1) == 0) && ok1;
     const int r_begin = i0 + wave * CSM_ROWS_PER_WAVE;
     const int r_end = min(r_begin + CSM_ROWS_PER_WAVE, ds.nx);
-    for (int i = r_begin; i < r_end; i++) {
-        const T *xp = feats + (ds.x_row0 + i) * D;   // wave-uniform address -> scalar loads
-        const T xx = norms[ds.x_row0 + i];
-        T a0 = 0, a1 = 0;
+    // wave-uniform: whole 128-column strip inside the matrix and every row 16-byte aligned
+    const bool full = (j0 + CSM_TN <= ds.ny) && ((ds.csm_pitch & 1) == 0) && ((ds.csm_off & 1) == 0);
+    if (full) {
+        for (int i = r_begin; i < r_end; i++) {
+            const T *xp = feats + (ds.x_row0 + i) * D;   // wave-uniform address -> scalar loads
+            T c0, c1;
+            if constexpr (MODE == 1) {
+                c0 = (T)i; c1 = yy0;
+            } else {
+                const T xx = norms[ds.x_row0 + i];
+                T a0 = 0, a1 = 0;
 #pragma unroll
-        for (int b = 0; b < D; b++) {
-            const T xb = xp[rot[b]];
-            a0 = fma(xb, y0[b], a0);
-            a1 = fma(xb, y1[b], a1);
-        }
-        const T c0 = clamp_sqrt(fma((T)-2, a0, xx + yy0));
-        const T c1 = clamp_sqrt(fma((T)-2, a1, xx + yy1));
-        T *dst = orow + (int64_t)i * ds.csm_pitch;
-        if (vec_ok) {
+                for (int b = 0; b < D; b++) {
+                    const T xb = xp[rot[b]];
+                    a0 = fma(xb, y0[b], a0);
+                    a1 = fma(xb, y1[b], a1);
+                }
+                c0 = csm_sqrt(fma((T)-2, a0, xx + yy0));
+                c1 = csm_sqrt(fma((T)-2, a1, xx + yy1));
+            }
+            T *dst = orow + (int64_t)i * ds.csm_pitch;
+            if constexpr (MODE == 2) {
+                if (c0 == (T)-1.25) dst[0] = c1;      // never true: keeps the arithmetic alive
+            } else
             if constexpr (sizeof(T) == 8) {
-                *reinterpret_cast<double2 *>(dst) = make_double2(c0, c1);
+                *reinterpret_cast<double2 *>(dst) = make_double2(c0, c1);   // one 16-byte store per lane
             } else {
                 *reinterpret_cast<float2 *>(dst) = make_float2(c0, c1);
             }
-        } else {
+        }
+    } else {
+        for (int i = r_begin; i < r_end; i++) {
+            const T *xp = feats + (ds.x_row0 + i) * D;
+            const T xx = norms[ds.x_row0 + i];
+            T a0 = 0, a1 = 0;
+#pragma unroll
+            for (int b = 0; b < D; b++) {
+                const T xb = xp[rot[b]];
+                a0 = fma(xb, y0[b], a0);
+                a1 = fma(xb, y1[b], a1);
+            }
+            const T c0 = csm_sqrt(fma((T)-2, a0, xx + yy0));
+            const T c1 = csm_sqrt(fma((T)-2, a1, xx + yy1));
+            T *dst = orow + (int64_t)i * ds.csm_pitch;
             if (ok0) dst[0] = c0;
             if (ok1) dst[1] = c1;
         }
@@ -486,6 +533,20 @@ int acoss_csm_batch_f32(const float *feats, const float *norms, int d, const aco
                         int K, int max_nx, int max_ny, float *csm, void *stream)
 {
     return launch_csm<float>(feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+
+// development probe (not part of the public ABI): the float64 d=12 CSM kernel in a probe MODE
+int acoss_dev_csm_probe(int mode, const double *feats, const double *norms, const acoss_pair_desc *descs,
+                        int K, int max_nx, int max_ny, double *csm, void *stream)
+{
+    const int tm = ceil_div(max_nx, CSM_TM), tn = ceil_div(max_ny, CSM_TN);
+    const unsigned blocks = (unsigned)((int64_t)K * tm * tn);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL((csm_kernel<double, 12, 1>), dim3(blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+    else if (mode == 2) hipLaunchKernelGGL((csm_kernel<double, 12, 2>), dim3(blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+    else if (mode == 3) hipLaunchKernelGGL((csm_kernel<double, 12, 3>), dim3(blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+    else hipLaunchKernelGGL((csm_kernel<double, 12, 0>), dim3(blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
+    return launch_check("csm_kernel probe");
 }
 
 int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,

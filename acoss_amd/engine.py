@@ -172,14 +172,17 @@ def binarize(S_buf, batch, kappa, mutual=True, out=None, work=None):
     return out
 
 
-def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None):
+def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None, mats_dev=None, scores=None):
     """SequenceAlignment.c recurrences over a batch of matrices.  kind in {'qmax','dmax','swc'}.
-    mats: numpy MAT_DESC array.  Returns the float32 score tensor (max cell per matrix)."""
+    mats: numpy MAT_DESC array (mats_dev: the same bytes already on the device, to keep the
+    upload out of a timed loop).  Returns the float32 score tensor (max cell per matrix)."""
     lib = _lib.load()
     K = len(mats)
     dev = B_buf.device
-    mats_dev = to_device_bytes(mats, dev)
-    scores = torch.empty(max(K, 1), dtype=torch.float32, device=dev)
+    if mats_dev is None:
+        mats_dev = to_device_bytes(mats, dev)
+    if scores is None:
+        scores = torch.empty(max(K, 1), dtype=torch.float32, device=dev)
     if max_cols is None:
         max_cols = int(mats["cols"].max()) if K else 0
     pp = ctypes.byref(params) if params is not None else None

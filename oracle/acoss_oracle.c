@@ -414,27 +414,60 @@ float orc_swc(const unsigned char *S, float *D, int N, int M)
 /* ------------------------------------------------------------------------------------ */
 /* Serra09.py:166-175 one pair's chain                                                   */
 /* ------------------------------------------------------------------------------------ */
+/* scratch for one pair of at most (max_n x max_n) frames; reused across pairs by one thread */
+typedef struct {
+    double *csm, *S;
+    uint8_t *B;
+    float *D;
+} pair_ws;
+
+static int ws_alloc(pair_ws *w, long max_nx, long max_ny)
+{
+    size_t cells = (size_t)max_nx * (size_t)max_ny;
+    w->csm = (double *)malloc(sizeof(double) * cells);
+    w->S = (double *)malloc(sizeof(double) * cells);
+    w->B = (uint8_t *)malloc(cells);
+    w->D = (float *)malloc(sizeof(float) * cells);
+    return (w->csm && w->S && w->B && w->D) ? 0 : -1;
+}
+
+static void ws_free(pair_ws *w)
+{
+    free(w->csm); free(w->S); free(w->B); free(w->D);
+}
+
+static int serra09_pair_ws(const double *Xi, const double *gi, long ni,
+                           const double *Xj, const double *gj, long nj,
+                           int d, int m, double kappa, int do_oti, pair_ws *w,
+                           double *qmax_out, double *dmax_out)
+{
+    long M = ni - m + 1, N = nj - m + 1;
+    if (M < 1 || N < 1) return -1;
+    int shift = do_oti ? orc_get_oti(gi, gj, d) : 0;        /* Serra09.py:166 */
+    orc_csm_f64(Xi, ni, Xj, nj, d, shift, w->csm);          /* :167-169 */
+    orc_sliding_csm_f64(w->csm, ni, nj, m, w->S);           /* :170 */
+    orc_csm_to_binary_mutual(w->S, M, N, kappa, w->B);      /* :171 */
+    memset(w->D, 0, sizeof(float) * (size_t)M * (size_t)N); /* :173 */
+    float q = orc_qmax(w->B, w->D, (int)M, (int)N);         /* :174 */
+    if (qmax_out) *qmax_out = (double)q / (double)(M + N);
+    if (dmax_out) {                                         /* skipped when only chroma_qmax is wanted */
+        float dm = orc_dmax(w->B, w->D, (int)M, (int)N);    /* :175 -- D not re-zeroed */
+        *dmax_out = (double)dm / (double)(M + N);
+    }
+    return 0;
+}
+
 int orc_serra09_pair(const double *Xi, const double *gi, long ni,
                      const double *Xj, const double *gj, long nj,
                      int d, int m, double kappa, int do_oti,
                      double *qmax_out, double *dmax_out)
 {
-    long M = ni - m + 1, N = nj - m + 1;
-    if (M < 1 || N < 1) return -1;
-    int shift = do_oti ? orc_get_oti(gi, gj, d) : 0;        /* Serra09.py:166 */
-    double *csm = (double *)malloc(sizeof(double) * (size_t)ni * nj);
-    double *S = (double *)malloc(sizeof(double) * (size_t)M * N);
-    uint8_t *B = (uint8_t *)malloc((size_t)M * N);
-    float *D = (float *)calloc((size_t)M * N, sizeof(float)); /* :173 */
-    orc_csm_f64(Xi, ni, Xj, nj, d, shift, csm);             /* :167-169 */
-    orc_sliding_csm_f64(csm, ni, nj, m, S);                 /* :170 */
-    orc_csm_to_binary_mutual(S, M, N, kappa, B);            /* :171 */
-    float q = orc_qmax(B, D, (int)M, (int)N);               /* :174 */
-    float dm = orc_dmax(B, D, (int)M, (int)N);              /* :175 -- D not re-zeroed */
-    if (qmax_out) *qmax_out = (double)q / (double)(M + N);
-    if (dmax_out) *dmax_out = (double)dm / (double)(M + N);
-    free(csm); free(S); free(B); free(D);
-    return 0;
+    pair_ws w;
+    if (ni < m || nj < m) return -1;
+    if (ws_alloc(&w, ni, nj) != 0) { ws_free(&w); return -1; }
+    int rc = serra09_pair_ws(Xi, gi, ni, Xj, gj, nj, d, m, kappa, do_oti, &w, qmax_out, dmax_out);
+    ws_free(&w);
+    return rc;
 }
 
 int orc_serra09_pairs(const double *feats, const int64_t *frame_off, const double *gchroma,
@@ -442,21 +475,37 @@ int orc_serra09_pairs(const double *feats, const int64_t *frame_off, const doubl
                       int nthreads, double *qmax_out, double *dmax_out)
 {
     int used = 1;
+    long max_n = 1;
+    for (long p = 0; p < K; p++) {
+        for (int s = 0; s < 2; s++) {
+            long n = frame_off[pairs[2 * p + s] + 1] - frame_off[pairs[2 * p + s]];
+            if (n > max_n) max_n = n;
+        }
+    }
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
     used = nthreads > 0 ? nthreads : omp_get_max_threads();
-#pragma omp parallel for schedule(dynamic, 1)
+#pragma omp parallel
 #endif
-    for (long p = 0; p < K; p++) {
-        int a = pairs[2 * p], b = pairs[2 * p + 1];
-        double q = 0.0, dm = 0.0;
-        orc_serra09_pair(feats + frame_off[a] * d, gchroma + (long)a * d,
-                         frame_off[a + 1] - frame_off[a],
-                         feats + frame_off[b] * d, gchroma + (long)b * d,
-                         frame_off[b + 1] - frame_off[b],
-                         d, m, kappa, do_oti, &q, &dm);
-        if (qmax_out) qmax_out[p] = q;
-        if (dmax_out) dmax_out[p] = dm;
+    {
+        pair_ws w;   /* one scratch per thread, reused: no allocator traffic inside the timed loop */
+        int ok = ws_alloc(&w, max_n, max_n) == 0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+        for (long p = 0; p < K; p++) {
+            int a = pairs[2 * p], b = pairs[2 * p + 1];
+            double q = 0.0, dm = 0.0;
+            if (ok)
+                serra09_pair_ws(feats + frame_off[a] * d, gchroma + (long)a * d,
+                                frame_off[a + 1] - frame_off[a],
+                                feats + frame_off[b] * d, gchroma + (long)b * d,
+                                frame_off[b + 1] - frame_off[b],
+                                d, m, kappa, do_oti, &w, &q, dmax_out ? &dm : NULL);
+            if (qmax_out) qmax_out[p] = q;
+            if (dmax_out) dmax_out[p] = dm;
+        }
+        ws_free(&w);
     }
     return used;
 }

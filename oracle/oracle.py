@@ -225,8 +225,9 @@ def serra09_pair(Xi, gi, Xj, gj, m=9, kappa=0.095, do_oti=True):
 
 
 def serra09_pairs(feats, frame_off, gchroma, pairs, m=9, kappa=0.095, do_oti=True,
-                  nthreads=1):
-    """Chain over many pairs of a concatenated corpus.  Returns (qmax, dmax, threads_used)."""
+                  nthreads=1, want_dmax=True):
+    """Chain over many pairs of a concatenated corpus.  Returns (qmax, dmax, threads_used);
+    want_dmax=False skips the dmax recurrence (dmax is then all zeros)."""
     feats = np.ascontiguousarray(feats, dtype=np.float64)
     frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
     gchroma = np.ascontiguousarray(gchroma, dtype=np.float64)
@@ -237,5 +238,5 @@ def serra09_pairs(feats, frame_off, gchroma, pairs, m=9, kappa=0.095, do_oti=Tru
     used = lib().orc_serra09_pairs(
         _d(feats), frame_off.ctypes.data_as(ctypes.POINTER(ctypes.c_int64)), _d(gchroma),
         pairs.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)), K, feats.shape[1], m,
-        float(kappa), int(bool(do_oti)), int(nthreads), _d(q), _d(dm))
+        float(kappa), int(bool(do_oti)), int(nthreads), _d(q), _d(dm) if want_dmax else None)
     return q, dm, used

@@ -1,0 +1,86 @@
+"""The plugin surface on the GPU: Serra09.similarity / all_pairwise / getEvalStatistics against the
+reference's own scores for the covers80-shaped corpus (BASELINE config 0/1) and against the oracle
+for file-based features."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config1_all_pairwise_scores_and_map_equal_reference(golden, tmp_path, monkeypatch):
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    monkeypatch.chdir(tmp_path)
+    g = golden("config1_scores")
+    corpus = synth.config1()
+    assert zlib.crc32(corpus.feats.tobytes()) == int(g["corpus_crc"][0])     # same inputs as the reference saw
+    alg = Serra09(corpus, shortname="config1", do_memmaps=True, cachedir=str(tmp_path / "cache"))
+    alg.all_pairwise(symmetric=True)
+    pairs = synth.all_pairs(corpus.n_songs)
+    for key in ("chroma_qmax", "chroma_dmax"):
+        got = np.asarray(alg.Ds[key])[pairs[:, 0], pairs[:, 1]]
+        assert np.array_equal(got, g[key].astype(np.float32)), key              # every one of 12720 scores
+        assert np.array_equal(np.asarray(alg.Ds[key]), np.asarray(alg.Ds[key]).T)   # CoverAlgorithm.py:180-182
+    MR, MRR, MDR, MAP, tops = alg.getEvalStatistics("chroma_qmax", verbose=False)
+    assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["stats_qmax"])
+    MR, MRR, MDR, MAP, tops = alg.getEvalStatistics("chroma_dmax", verbose=False)
+    assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["stats_dmax"])
+    alg.cleanup_memmap()
+
+
+def test_similarity_contract(golden, tmp_path):
+    """Six keys, float64 arrays of length K, Ds written in place when do_memmaps (Serra09.py:158-196)."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    g = golden("serra09_mini")
+    corpus = synth.Corpus(g["feats"], g["frame_off"], g["gchroma"], [str(x) for x in g["labels"]])
+    off = g["frame_off"]
+    corpus.mfcc = [np.ascontiguousarray(g["mfcc"][off[i]:off[i + 1]].T) for i in range(corpus.n_songs)]
+    alg = Serra09(corpus, shortname="mini", do_memmaps=True, cachedir=str(tmp_path / "cache"))
+    idxs = g["pairs"][:20].astype(np.int64)
+    with pytest.warns(UserWarning):
+        sims = alg.similarity(idxs)
+    assert sorted(sims) == sorted(Serra09.KEYS)
+    for key in sims:
+        assert sims[key].dtype == np.float64 and sims[key].shape == (20,)
+    assert np.array_equal(sims["chroma_qmax"], g["chroma_qmax"][:20])
+    assert np.array_equal(sims["chroma_dmax"], g["chroma_dmax"][:20])
+    assert np.array_equal(sims["mfcc_qmax"], g["mfcc_qmax"][:20])
+    assert np.array_equal(sims["mfcc_dmax"], g["mfcc_dmax"][:20])
+    assert np.all(sims["ssms_scatter_qmax"] == 0)
+    assert np.array_equal(np.asarray(alg.Ds["chroma_qmax"])[idxs[:, 0], idxs[:, 1]],
+                          g["chroma_qmax"][:20].astype(np.float32))
+    # do_memmaps=False: no Ds attribute at all (CoverAlgorithm.py:48-51)
+    alg2 = Serra09(corpus, shortname="mini2", do_memmaps=False)
+    assert not hasattr(alg2, "Ds")
+    assert np.array_equal(alg2.similarity(idxs[:3])["chroma_qmax"], g["chroma_qmax"][:3])
+
+
+def test_feature_files_and_downsampling(orc, tmp_path):
+    """Songs on disk (.npz with the reference's field names), full-resolution chroma aggregated by
+    block medians, MFCC by block means, OTI from the full-resolution global chroma."""
+    from acoss_amd import Serra09 as S9
+    from acoss_amd import synth
+    full = synth.make_corpus(3, 2, seed=31, lengths=lambda r: r.integers(900, 1400))
+    rng = np.random.default_rng(32)
+    data = tmp_path / "features"
+    data.mkdir()
+    for i in range(full.n_songs):
+        x = full.song(i)
+        np.savez(str(data / ("song_%02d.npz" % i)), hpcp=x.astype(np.float32), crema=x,
+                 mfcc_htk=np.cumsum(rng.standard_normal((13, x.shape[0])), axis=1).astype(np.float32),
+                 label=full.labels[i])
+    alg = S9.Serra09(str(data), chroma_type="crema", shortname="files", downsample_fac=8, do_memmaps=False,
+                     cachedir=str(tmp_path / "cache"))
+    assert alg.N == 6
+    idxs = np.array([[0, 1], [2, 3], [4, 1], [5, 5]])
+    with pytest.warns(UserWarning):
+        sims = alg.similarity(idxs)
+    assert alg.cliques[full.labels[0]] == {0, 1}
+    for t, (i, j) in enumerate(idxs):
+        fi, fj = alg.load_features(i), alg.load_features(j)
+        assert np.array_equal(fi["gchroma"], S9.global_chroma(full.song(i)))
+        q, d = orc.serra09_pair(fi["chroma"].T, fi["gchroma"], fj["chroma"].T, fj["gchroma"], m=9, kappa=0.095)
+        assert sims["chroma_qmax"][t] == q and sims["chroma_dmax"][t] == d

@@ -1,0 +1,110 @@
+"""Host logic of the plugin layer that needs no GPU: evaluation statistics against the reference's
+own outputs, feature aggregation, batch indexing and checkpoint format."""
+import os
+
+import numpy as np
+import pytest
+
+from acoss_amd.CoverAlgorithm import CoverAlgorithm
+from acoss_amd import Serra09 as S9
+
+
+def _alg(tmp_path, N, name="t"):
+    alg = CoverAlgorithm.__new__(CoverAlgorithm)
+    alg.name, alg.shortname, alg.cachedir = "Golden", name, str(tmp_path)
+    alg.cliques, alg.all_feats, alg.corpus = {}, {}, None
+    alg.filepaths = ["x"] * N
+    alg.N = N
+    alg.do_memmaps = False
+    alg.similarity_types = ["main"]
+    return alg
+
+
+def test_eval_statistics_match_reference(golden, tmp_path, monkeypatch):
+    monkeypatch.chdir(tmp_path)
+    g = golden("evalstats")
+    for c in range(int(g["n_cases"])):
+        D, labels = g["e%d_D" % c], g["e%d_labels" % c]
+        alg = _alg(tmp_path, len(labels), "golden%d" % c)
+        alg.Ds = {"main": D}
+        for i, lab in enumerate(labels):
+            alg.cliques.setdefault("clique_%d" % lab, set()).add(i)
+        MR, MRR, MDR, MAP, tops = alg.getEvalStatistics("main", verbose=False)
+        assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["e%d_stats" % c]), c
+        # CSV columns of CoverAlgorithm.py:404-417
+        lines = open("results_golden%d.csv" % c).read().splitlines()
+        assert lines[0] == "name, MR, MRR, MDR, MAP,Top-1,Top-10,Top-100,Top-1000"
+        assert lines[1].startswith("Golden_main,")
+
+
+def test_eval_statistics_equal_loop_oracle_on_random_ties(tmp_path, monkeypatch):
+    from oracle.evalstats import get_eval_statistics
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(17)
+    for trial in range(5):
+        sizes = rng.integers(1, 6, size=12)
+        N = int(sizes.sum())
+        labels = np.repeat(np.arange(len(sizes)), sizes)[rng.permutation(N)]
+        D = np.round(rng.random((N, N)) * 6) / 6            # heavy ties
+        D = np.triu(D, 1); D = (D + D.T).astype(np.float32)
+        alg = _alg(tmp_path, N)
+        alg.Ds = {"main": D}
+        for i, lab in enumerate(labels):
+            alg.cliques.setdefault("c%d" % lab, set()).add(i)
+        got = alg.getEvalStatistics("main", verbose=False, write_csv=False)
+        exp = get_eval_statistics(D, alg.cliques)
+        assert np.array_equal(np.array(list(got[:4]) + list(got[4])), np.array(list(exp[:4]) + list(exp[4])))
+
+
+def test_config1_map_from_reference_scores(golden, tmp_path, monkeypatch):
+    """MAP of the covers80-shaped corpus from the reference's own score vectors."""
+    from acoss_amd import sharding, synth
+    monkeypatch.chdir(tmp_path)
+    g = golden("config1_scores")
+    pairs = synth.all_pairs(160)
+    labels = ["clique_%05d" % (i // 2) for i in range(160)]
+    for key, stats in (("chroma_qmax", g["stats_qmax"]), ("chroma_dmax", g["stats_dmax"])):
+        alg = _alg(tmp_path, 160)
+        alg.Ds = {key: sharding.scatter_to_matrix(pairs, g[key], 160)}
+        for i, lab in enumerate(labels):
+            alg.cliques.setdefault(lab, set()).add(i)
+        got = alg.getEvalStatistics(key, verbose=False, write_csv=False)
+        assert np.array_equal(np.array(list(got[:4]) + list(got[4])), stats)
+
+
+def test_global_chroma_and_block_aggregate():
+    rng = np.random.default_rng(2)
+    c = rng.random((1234, 12))
+    g = S9.global_chroma(c)
+    assert g.max() == 1.0 and g.shape == (12,)
+    with pytest.raises(IOError):
+        S9.global_chroma(c.T)                                   # Serra09.py:26-27
+    med = S9.block_aggregate(c.T, 40, np.median)
+    assert med.shape == (12, 31)                                # ceil(1234/40) blocks, last one partial
+    assert np.array_equal(med[:, 0], np.median(c[:40].T, axis=1))
+    assert np.array_equal(med[:, -1], np.median(c[1200:].T, axis=1))
+
+
+def test_subbatch_indexing_matches_reference_rule(tmp_path):
+    """do_batch_subbatch pairs: lower-triangular blocks, row >= col, diagonal included
+    (CoverAlgorithm.py:232-244)."""
+    seen = []
+
+    class Probe(CoverAlgorithm):
+        def similarity(self, idxs):
+            seen.append(np.array(idxs))
+            return {"main": np.arange(len(idxs), dtype=np.float64)}
+
+    alg = Probe("Probe", datapath=str(tmp_path), shortname="p", cachedir=str(tmp_path / "cache"), do_memmaps=False)
+    alg.filepaths = ["x"] * 8
+    alg.N = 8
+    s = alg.do_batch_subbatch(4, 0, 4, 0, 0)      # block (0,0): songs 0..3 x 0..3
+    idxs = s["idxs"]
+    assert np.all(idxs[:, 0] >= idxs[:, 1]) and len(idxs) == 10 and [2, 2] in idxs.tolist()
+    s = alg.do_batch_subbatch(4, 1, 4, 0, 0)      # block (1,0): rows 4..7, cols 0..3 -> all 16
+    assert len(s["idxs"]) == 16 and s["idxs"][:, 0].min() == 4
+    # checkpointed do_batch resumes: second call computes nothing new
+    alg.do_batch(4, 2, 2)
+    n_calls = len(seen)
+    out = alg.do_batch(4, 2, 2)
+    assert len(seen) == n_calls and len(out["idxs"]) == 10 and os.path.exists(str(tmp_path / "cache" / "Probe_p_2.npz"))

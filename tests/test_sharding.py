@@ -1,0 +1,75 @@
+"""Pair sharding and the path's single collective, on CPU with the gloo backend (world_size 2 and 3).
+The same code runs under "nccl" (RCCL over xGMI) in bench.py and CoverAlgorithm.all_pairwise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from acoss_amd import sharding, synth
+
+
+def test_shards_partition_the_pair_list_and_balance_cost():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(200, 1200, size=60)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    pairs = synth.all_pairs(60)
+    costs = sharding.pair_costs(off, pairs, win=9)
+    assert costs[0] == (lens[0] - 8) * (lens[1] - 8)
+    for world in (1, 2, 4, 8):
+        shards = [sharding.shard_indices(costs, world, r) for r in range(world)]
+        allidx = np.sort(np.concatenate(shards))
+        assert np.array_equal(allidx, np.arange(len(pairs)))            # a partition
+        sizes = [len(s) for s in shards]
+        assert max(sizes) - min(sizes) <= 1
+        loads = np.array([costs[s].sum() for s in shards], dtype=np.float64)
+        assert loads.max() / loads.mean() < 1.01                        # ragged lengths balance
+
+
+def test_scatter_to_matrix_symmetrises_like_the_reference():
+    pairs = synth.all_pairs(5)
+    scores = np.arange(1, len(pairs) + 1, dtype=np.float64)
+    D = sharding.scatter_to_matrix(pairs, scores, 5)
+    assert D.dtype == np.float32 and np.array_equal(D, D.T) and np.all(np.diag(D) == 0)
+    assert D[0, 1] == 1 and D[3, 4] == len(pairs)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, K, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        costs = (np.arange(K) * 7919) % 1000 + 1
+        mine = sharding.shard_indices(costs, world, rank)
+        truth = np.sin(np.arange(K)).astype(np.float32)                  # the "score" of pair k
+        local = torch.from_numpy(truth[mine])
+        full = sharding.gather_scores(local, mine, K)
+        assert full.dtype == torch.float32
+        assert np.array_equal(full.numpy(), truth), "rank %d gathered wrong scores" % rank
+        np.save(os.path.join(tmp, "ok_%d.npy" % rank), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,K", [(2, 101), (3, 64), (2, 1)])
+def test_gather_scores_gloo(tmp_path, world, K):
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, K, str(tmp_path)), nprocs=world, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok_%d.npy" % r)) for r in range(world))
+
+
+def test_gather_scores_single_process():
+    idx = np.array([4, 0, 2])
+    out = sharding.gather_scores(torch.tensor([1.0, 2.0, 3.0]), idx, 6)
+    assert out.tolist() == [2.0, 0.0, 3.0, 0.0, 1.0, 0.0]
