@@ -54,6 +54,13 @@ SIGNATURES = {
     "acoss_oti_batch": (_i, [_vp, _i, _vp, _i, _vp]),
     "acoss_csm_batch_f64": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_csm_batch_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "acoss_xpack_elems": (_i64, [_i, _i]),
+    "acoss_pack_x_f64": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "acoss_pack_x_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
+    "acoss_csm_packed_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "acoss_csm_packed_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "acoss_crp_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "acoss_crp_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acoss_sliding_batch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acoss_sliding_batch_f32": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acoss_binarize_work_bytes": (_sz, [_i, _i, _i, _i]),

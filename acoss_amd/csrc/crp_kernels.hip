@@ -4,21 +4,11 @@
 // gfx950 (CDNA4) only: wave64, DPP reductions, scalar (SGPR) broadcast of wave-uniform rows.
 #include "common.h"
 #include "wave_ops.h"
+#include "kernel_utils.h"
 
 #include <math.h>
 
 namespace acoss {
-
-// ---------------------------------------------------------------------------------------------
-// XCD-aware block remap: hardware deals consecutive block ids round-robin over the 8 XCDs; this
-// maps them back so that logically consecutive blocks (tiles of one pair, which share the two
-// songs' feature rows) run on one XCD and hit its L2.  Bijective for any grid size.
-// ---------------------------------------------------------------------------------------------
-__device__ inline int xcd_remap(int b, int nblk)
-{
-    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
-    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-}
 
 // ---------------------------------------------------------------------------------------------
 // per-frame squared norms (FMA chain in bin order; this order is part of the kernels' contract:
@@ -103,28 +93,6 @@ __device__ inline T clamp_sqrt(T c)
     c = c < (T)0 ? (T)0 : c;   // CRPUtils.py:83
     return sqrt(c);
 }
-
-// sqrt(max(c, 0)) for the CSM epilogue.  float64: v_rsq_f64 seed, one Goldschmidt step and two
-// Newton corrections (the sequence the compiler's own sqrt uses, correctly rounded), but without
-// the per-element exponent rescaling and class tests: zero flows through the iteration exactly
-// (0 * finite seed), and the only inputs the fast form cannot take -- positive values below
-// 2^-900 -- are sent to the library sqrt by a wave-uniform branch that is never taken on real
-// features.
-__device__ inline double csm_sqrt(double c)
-{
-    c = fmax(c, 0.0);
-    const double tiny = 0x1.0p-900;
-    if (__builtin_expect(__any(c > 0.0 && c < tiny), 0)) return sqrt(c);
-    const double y = __builtin_amdgcn_rsq(fmax(c, tiny));
-    double g = c * y, h = 0.5 * y;
-    const double r = fma(-h, g, 0.5);
-    g = fma(g, r, g);
-    h = fma(h, r, h);
-    g = fma(fma(-g, g, c), h, g);
-    g = fma(fma(-g, g, c), h, g);
-    return g;
-}
-__device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
 
 // MODE (development probes, product = 0): 1 = stores only (no arithmetic), 2 = arithmetic only (store
 // suppressed), 3 = assume shift == 0 (contiguous scalar loads of the x frame)
@@ -323,34 +291,106 @@ __device__ inline bool trivial_select(int k, int n, SelectResult &r)
     return false;
 }
 
+// Rows: each wave walks SEL_ROWS_PER_WAVE consecutive rows; while it selects in row r the 16-byte
+// loads of row r+1 are already in flight (two register buffers, statically alternated), so the
+// HBM latency of a row hides behind the selection of the previous one.  Lane l holds elements
+// 128*q + 2*l + {0,1} of the row (one 16-byte load per q).
+constexpr int SEL_ROWS_PER_WAVE = 8;
+
+// Branch-free: positions past the row end are clamped to the row's last aligned pair (in bounds,
+// the row pitch is even) and masked out when the keys are formed, so all EPL/2 loads of a row issue
+// back to back.
 template <int EPL>
+__device__ inline void load_row_pairs(const double *row, int N, int lane, bool vec_ok, double (&buf)[EPL])
+{
+    if (vec_ok) {   // wave-uniform
+        const int last = ((N + 1) & ~1) - 2;
+#pragma unroll
+        for (int q = 0; q < EPL / 2; q++) {
+            const int j = min(128 * q + 2 * lane, last);
+            const double2 v = *reinterpret_cast<const double2 *>(row + j);
+            buf[2 * q] = v.x;
+            buf[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < EPL / 2; q++) {
+            const int j = 128 * q + 2 * lane;
+            buf[2 * q] = row[min(j, N - 1)];
+            buf[2 * q + 1] = row[min(j + 1, N - 1)];
+        }
+    }
+}
+
+template <int EPL>
+__device__ inline SelectResult select_from_buf(const double (&buf)[EPL], int N, int k, int lane)
+{
+    SelectResult res;
+    if (trivial_select(k, N, res)) return res;
+    uint64_t key[EPL];
+    int idx[EPL];
+#pragma unroll
+    for (int e = 0; e < EPL; e++) {
+        idx[e] = 128 * (e >> 1) + 2 * lane + (e & 1);
+        key[e] = idx[e] < N ? f64_key(buf[e]) : ~0ull;
+    }
+    return wave_select_kth<EPL>(key, idx, N, k);
+}
+
+// MODE (development probes, product = 0): 1 = row loads only, 2 = selection only (synthetic values)
+template <int EPL, int MODE = 0>
 __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restrict__ S,
                                                           const acoss_pair_desc *__restrict__ descs,
                                                           int win, double kappa_k_fixed, int k_mode,
                                                           ThreshWork w, int rows_blocks)
 {
-    const int p = blockIdx.x / rows_blocks;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / rows_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int i = (blockIdx.x % rows_blocks) * 4 + wave;
+    const int r0 = ((lb % rows_blocks) * 4 + wave) * SEL_ROWS_PER_WAVE;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    if (i >= M) return;
+    if (r0 >= M) return;
+    const int r1 = min(r0 + SEL_ROWS_PER_WAVE, M);
     const int lane = threadIdx.x & 63;
     // neighbour count from the number of columns (CRPUtils.py:190-193); k_mode 0: fraction
     // (half-even rounding, rint under the default rounding mode), 1: absolute count, 2: all
-    int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)N) : (k_mode == 1 ? (int)kappa_k_fixed : N);
-    SelectResult res;
-    if (!trivial_select(k, N, res)) {
-        const double *row = S + ds.crp_off + (int64_t)i * ds.crp_pitch;
-        uint64_t key[EPL];
+    const int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)N) : (k_mode == 1 ? (int)kappa_k_fixed : N);
+    const double *base = S + ds.crp_off;
+    const bool vec_ok = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);
+    uint64_t *thr = w.row_thr + (int64_t)p * w.max_m;
+    int *cut = w.row_cut + (int64_t)p * w.max_m;
+    double bufA[EPL], bufB[EPL];
+    if constexpr (MODE == 1) {
+        for (int i = r0; i < r1; i++) {
+            load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, bufA);
+            double acc = 0;
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            const int j = e * 64 + lane;
-            key[e] = j < N ? f64_key(row[j]) : ~0ull;
+            for (int e = 0; e < EPL; e++) acc += bufA[e];
+            if (acc == 1.2345) thr[i] = 0;
         }
-        res = wave_select_kth<EPL>(key, N, k);
+        return;
     }
-    store_uniform_select(k, N, w.row_thr + (int64_t)p * w.max_m + i, w.row_cut + (int64_t)p * w.max_m + i, res);
+    if constexpr (MODE == 2) {
+        for (int i = r0; i < r1; i++) {
+#pragma unroll
+            for (int e = 0; e < EPL; e++) bufA[e] = (double)((lane * 2654435761u + e * 40503u + i * 97u) & 0xfffff) * 1e-3 + 0.5;
+            SelectResult res = select_from_buf<EPL>(bufA, N, k, lane);
+            store_uniform_select(k, N, thr + i, cut + i, res);
+        }
+        return;
+    }
+    load_row_pairs<EPL>(base + (int64_t)r0 * ds.crp_pitch, N, lane, vec_ok, bufA);
+    for (int i = r0; i < r1; i += 2) {
+        if (i + 1 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 1) * ds.crp_pitch, N, lane, vec_ok, bufB);
+        SelectResult res = select_from_buf<EPL>(bufA, N, k, lane);
+        store_uniform_select(k, N, thr + i, cut + i, res);
+        if (i + 1 < r1) {
+            if (i + 2 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 2) * ds.crp_pitch, N, lane, vec_ok, bufA);
+            res = select_from_buf<EPL>(bufB, N, k, lane);
+            store_uniform_select(k, N, thr + i + 1, cut + i + 1, res);
+        }
+    }
 }
 
 constexpr int SEL_COLS_PER_BLOCK = 8;
@@ -362,17 +402,25 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
                                                           ThreshWork w, int col_blocks)
 {
     extern __shared__ double colbuf[];   // [8][ldc]
-    const int p = blockIdx.x / col_blocks;
-    const int j0 = (blockIdx.x % col_blocks) * SEL_COLS_PER_BLOCK;
+    // neighbouring column blocks read the two 64-byte halves of the same lines: keep them on one XCD
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / col_blocks;
+    const int j0 = (lb % col_blocks) * SEL_COLS_PER_BLOCK;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
     if (j0 >= N) return;
     constexpr int ldc = EPL * 64 + 2;
     const double *base = S + ds.crp_off;
-    // 512 threads: 64 rows x 8 columns per sweep, 64-byte segments per row
-    for (int r0 = 0; r0 < M; r0 += 64) {
-        const int r = r0 + (threadIdx.x >> 3), c = threadIdx.x & 7;
-        if (r < M && j0 + c < N) colbuf[c * ldc + r] = base[(int64_t)r * ds.crp_pitch + j0 + c];
+    // 512 threads: 64 rows x 8 columns per sweep, 64-byte segments per row.  Fully unrolled and
+    // branch-free (clamped addresses) so that all EPL loads of a thread are in flight together.
+    {
+        const int c = threadIdx.x & 7, rr = threadIdx.x >> 3;
+        const int cc = min(j0 + c, N - 1);
+        double tmp[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) tmp[e] = base[(int64_t)min(e * 64 + rr, M - 1) * ds.crp_pitch + cc];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) colbuf[c * ldc + e * 64 + rr] = tmp[e];
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -383,54 +431,80 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
     SelectResult res;
     if (!trivial_select(k, M, res)) {
         uint64_t key[EPL];
+        int idx[EPL];
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            const int i = e * 64 + lane;
-            key[e] = i < M ? f64_key(colbuf[wave * ldc + i]) : ~0ull;
+            idx[e] = e * 64 + lane;
+            key[e] = idx[e] < M ? f64_key(colbuf[wave * ldc + idx[e]]) : ~0ull;
         }
-        res = wave_select_kth<EPL>(key, M, k);
+        res = wave_select_kth<EPL>(key, idx, M, k);
     }
     store_uniform_select(k, M, w.col_thr + (int64_t)p * w.max_n + j, w.col_cut + (int64_t)p * w.max_n + j, res);
 }
 
-// B[i][j] = row rule (and column rule when mutual): 4 columns per thread, one dword store.
+// B[i][j] = row rule (and column rule when mutual).  A thread owns 4 adjacent columns (its column
+// thresholds stay in registers) and walks MASK_ROWS rows, with all of its 32-byte row loads issued
+// before the first compare; a wave covers 256 contiguous columns (2 KB) of each row.
+constexpr int MASK_ROWS = 8;
+
 __global__ __launch_bounds__(256) void mask_kernel(const double *__restrict__ S,
                                                    const acoss_pair_desc *__restrict__ descs, int win,
-                                                   int mutual, ThreshWork w, int blocks_per_pair,
+                                                   int mutual, ThreshWork w, int col_blocks, int row_blocks,
                                                    uint8_t *__restrict__ B)
 {
-    const int p = blockIdx.x / blocks_per_pair;
+    const int per_pair = col_blocks * row_blocks;
+    const int p = blockIdx.x / per_pair, t = blockIdx.x % per_pair;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    const int quads = (N + 3) >> 2;
-    const int64_t total = (int64_t)M * quads;
-    for (int64_t q = (int64_t)(blockIdx.x % blocks_per_pair) * 256 + threadIdx.x; q < total;
-         q += (int64_t)blocks_per_pair * 256) {
-        const int i = (int)(q / quads), j = (int)(q % quads) * 4;
-        const uint64_t rt = w.row_thr[(int64_t)p * w.max_m + i];
-        const int rc = w.row_cut[(int64_t)p * w.max_m + i];
-        const double *row = S + ds.crp_off + (int64_t)i * ds.crp_pitch;
-        uint8_t *brow = B + ds.crp_off + (int64_t)i * ds.crp_pitch;
+    const int j = (t % col_blocks) * 1024 + threadIdx.x * 4;
+    const int i0 = (t / col_blocks) * MASK_ROWS;
+    if (i0 >= M || j >= N) return;
+    const bool vec = ((ds.crp_pitch & 3) == 0) && ((ds.crp_off & 3) == 0) && j + 3 < N;
+    uint64_t ct[4];
+    int cc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+        const int jc = min(j + c, N - 1);
+        ct[c] = mutual ? w.col_thr[(int64_t)p * w.max_n + jc] : ~0ull;
+        cc[c] = mutual ? w.col_cut[(int64_t)p * w.max_n + jc] : 0x7fffffff;
+    }
+    const double *base = S + ds.crp_off + j;
+    double v[MASK_ROWS][4];
+    uint64_t rt[MASK_ROWS];
+    int rc[MASK_ROWS];
+#pragma unroll
+    for (int r = 0; r < MASK_ROWS; r++) {
+        const int i = min(i0 + r, M - 1);
+        const double *row = base + (int64_t)i * ds.crp_pitch;
+        if (vec) {
+            const double2 a = *reinterpret_cast<const double2 *>(row), b = *reinterpret_cast<const double2 *>(row + 2);
+            v[r][0] = a.x; v[r][1] = a.y; v[r][2] = b.x; v[r][3] = b.y;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; c++) v[r][c] = row[min(c, N - 1 - j)];
+        }
+        rt[r] = w.row_thr[(int64_t)p * w.max_m + i];
+        rc[r] = w.row_cut[(int64_t)p * w.max_m + i];
+    }
+#pragma unroll
+    for (int r = 0; r < MASK_ROWS; r++) {
+        const int i = i0 + r;
+        if (i >= M) break;
         uint32_t packed = 0;
 #pragma unroll
         for (int c = 0; c < 4; c++) {
-            if (j + c < N) {
-                const uint64_t key = f64_key(row[j + c]);
-                bool on = key < rt || (key == rt && j + c <= rc);
-                if (mutual) {
-                    const uint64_t ct = w.col_thr[(int64_t)p * w.max_n + j + c];
-                    const int cc = w.col_cut[(int64_t)p * w.max_n + j + c];
-                    on = on && (key < ct || (key == ct && i <= cc));
-                }
-                packed |= (on ? 1u : 0u) << (8 * c);
-            }
+            const uint64_t key = f64_key(v[r][c]);
+            bool on = key < rt[r] || (key == rt[r] && j + c <= rc[r]);
+            on = on && (key < ct[c] || (key == ct[c] && i <= cc[c]));
+            packed |= (on ? 1u : 0u) << (8 * c);
         }
-        if (j + 3 < N && (ds.crp_pitch & 3) == 0 && (ds.crp_off & 3) == 0) {
-            *reinterpret_cast<uint32_t *>(brow + j) = packed;
+        uint8_t *brow = B + ds.crp_off + (int64_t)i * ds.crp_pitch + j;
+        if (vec) {
+            *reinterpret_cast<uint32_t *>(brow) = packed;
         } else {
 #pragma unroll
             for (int c = 0; c < 4; c++)
-                if (j + c < N) brow[j + c] = (uint8_t)((packed >> (8 * c)) & 0xff);
+                if (j + c < N) brow[c] = (uint8_t)((packed >> (8 * c)) & 0xff);
         }
     }
 }
@@ -535,6 +609,26 @@ int acoss_csm_batch_f32(const float *feats, const float *norms, int d, const aco
     return launch_csm<float>(feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
 }
 
+// development probe (not part of the public ABI): select_rows in a probe MODE
+int acoss_dev_select_probe(int mode, const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                           int max_ny, double kappa, void *work, void *stream)
+{
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    ThreshWork w;
+    w.max_m = max_m; w.max_n = max_n;
+    w.row_thr = (uint64_t *)work;
+    w.col_thr = w.row_thr + (size_t)K * max_m;
+    w.row_cut = (int *)(w.col_thr + (size_t)K * max_n);
+    w.col_cut = w.row_cut + (size_t)K * max_m;
+    const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
+    const unsigned blocks = (unsigned)((int64_t)K * rb);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL((select_rows_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
+    else if (mode == 2) hipLaunchKernelGGL((select_rows_kernel<16, 2>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
+    else hipLaunchKernelGGL((select_rows_kernel<16, 0>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
+    return launch_check("select_rows probe");
+}
+
 // development probe (not part of the public ABI): the float64 d=12 CSM kernel in a probe MODE
 int acoss_dev_csm_probe(int mode, const double *feats, const double *norms, const acoss_pair_desc *descs,
                         int K, int max_nx, int max_ny, double *csm, void *stream)
@@ -597,7 +691,7 @@ int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, i
     int mode;
     kappa_mode(kappa, kv, mode);
     {
-        const int rb = ceil_div(max_m, 4);
+        const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
         if (max_n <= 1024)
             hipLaunchKernelGGL(select_rows_kernel<16>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
         else
@@ -620,9 +714,8 @@ int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, i
         if (rc) return rc;
     }
     {
-        const int64_t quads = (int64_t)max_m * ((max_n + 3) / 4);
-        const int bpp = (int)(ceil_div64(quads, 256 * 4) < 1 ? 1 : ceil_div64(quads, 256 * 4));
-        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((int64_t)K * bpp)), dim3(256), 0, st, S, descs, win, mutual, w, bpp, B);
+        const int cbk = ceil_div(max_n, 1024), rbk = ceil_div(max_m, MASK_ROWS);
+        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((int64_t)K * cbk * rbk)), dim3(256), 0, st, S, descs, win, mutual, w, cbk, rbk, B);
         return launch_check("mask_kernel");
     }
 }

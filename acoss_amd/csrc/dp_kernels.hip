@@ -42,10 +42,13 @@ __device__ inline void load_mask_row(const uint8_t *row, int j0, int N, bool ali
         for (int q = 0; q < NW; q++) w[q] = 0;
         return;
     }
-    if (aligned && j0 + NW * 4 <= N) {
+    if (aligned) {
+        // wave-uniform branch; lanes past the row end re-read its last aligned 16 bytes (in bounds:
+        // the pitch is a multiple of 16) -- their cells are masked out by the column validity test
+        const int last = ((N + 15) & ~15) - 16;
 #pragma unroll
         for (int q = 0; q < NW; q += 4) {
-            const uint4 v = *reinterpret_cast<const uint4 *>(row + j0 + 4 * q);
+            const uint4 v = *reinterpret_cast<const uint4 *>(row + min(j0 + 4 * q, last));
             w[q] = v.x; w[q + 1] = v.y; w[q + 2] = v.z; w[q + 3] = v.w;
         }
     } else {
@@ -119,97 +122,115 @@ __global__ __launch_bounds__(256) void dp_wave_kernel(const uint8_t *__restrict_
     }
 
     float best = 0.0f;
-    unsigned s0[NW], snext[NW];
-    load_mask_row<NW>(sbase + (int64_t)FIRST * md.s_pitch, j0, N, aligned, snext);
-    for (int i = FIRST; i < M; i++) {
+    // Mask rows are prefetched PF rows ahead into a register ring (the row sweep is a serial chain:
+    // without this every step would expose a full HBM/L2 round trip).  The ring is indexed
+    // statically by unrolling the row loop PF times; the slot a row is consumed from is refilled at
+    // once with the row PF steps ahead.
+    constexpr int PF = (NW <= 4) ? 8 : 4;
+    unsigned ring[PF][NW];
 #pragma unroll
-        for (int q = 0; q < NW; q++) s0[q] = snext[q];
-        if (i + 1 < M) load_mask_row<NW>(sbase + (int64_t)(i + 1) * md.s_pitch, j0, N, aligned, snext);
+    for (int u = 0; u < PF; u++) {
+        if (FIRST + u < M) load_mask_row<NW>(sbase + (int64_t)(FIRST + u) * md.s_pitch, j0, N, aligned, ring[u]);
+        else load_mask_row<NW>(nullptr, j0, N, aligned, ring[u]);
+    }
+    auto do_row = [&](const int i, const unsigned (&s0)[NW]) {
+            // left halo from lane l-1 (lane 0 gets zeros; its columns < FIRST are never computed)
+            const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
+            const float h1c = lane_shr1(d1[CPL - 3], 0.f);
+            const float h2a = lane_shr1(d2[CPL - 1], 0.f), h3a = lane_shr1(d3[CPL - 1], 0.f);
+            const unsigned hs0 = (unsigned)lane_shr1((int)s0[NW - 1], 0);
+            const unsigned hs1 = (unsigned)lane_shr1((int)s1[NW - 1], 0);
+            const unsigned hs2 = (unsigned)lane_shr1((int)s2[NW - 1], 0);
+            const unsigned hs3 = (unsigned)lane_shr1((int)s3[NW - 1], 0);
 
-        // left halo from lane l-1 (lane 0 gets zeros; its columns < FIRST are never computed)
-        const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
-        const float h1c = lane_shr1(d1[CPL - 3], 0.f);
-        const float h2a = lane_shr1(d2[CPL - 1], 0.f), h3a = lane_shr1(d3[CPL - 1], 0.f);
-        const unsigned hs0 = (unsigned)lane_shr1((int)s0[NW - 1], 0);
-        const unsigned hs1 = (unsigned)lane_shr1((int)s1[NW - 1], 0);
-        const unsigned hs2 = (unsigned)lane_shr1((int)s2[NW - 1], 0);
-        const unsigned hs3 = (unsigned)lane_shr1((int)s3[NW - 1], 0);
-
-        float nd[CPL];
+            float nd[CPL];
 #pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int j = j0 + c;
-            const float p_diag = c >= 1 ? d1[c - 1] : h1a;                       // D[i-1][j-1]
-            const float p_up2 = c >= 1 ? d2[c - 1] : h2a;                        // D[i-2][j-1]
-            const float p_left2 = c >= 2 ? d1[c - 2] : (c == 1 ? h1a : h1b);     // D[i-1][j-2]
-            const unsigned cur = seg_byte<NW>(s0, hs0, c);
-            float v;
-            if (KIND == KIND_QMAX) {
-                if (cur == 1u) {
-                    v = max3f(p_diag, p_up2, p_left2) + 1.0f;
-                } else {
-                    const float g1 = seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
-                    const float g2 = seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
-                    const float g3 = seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
-                    v = fmaxf(max3f(p_diag - g1, p_up2 - g2, p_left2 - g3), 0.0f);
+            for (int c = 0; c < CPL; c++) {
+                const int j = j0 + c;
+                const float p_diag = c >= 1 ? d1[c - 1] : h1a;                       // D[i-1][j-1]
+                const float p_up2 = c >= 1 ? d2[c - 1] : h2a;                        // D[i-2][j-1]
+                const float p_left2 = c >= 2 ? d1[c - 2] : (c == 1 ? h1a : h1b);     // D[i-1][j-2]
+                const unsigned cur = seg_byte<NW>(s0, hs0, c);
+                float v;
+                if (KIND == KIND_QMAX) {
+                    if (cur == 1u) {
+                        v = max3f(p_diag, p_up2, p_left2) + 1.0f;
+                    } else {
+                        const float g1 = seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                        const float g2 = seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                        const float g3 = seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
+                        v = fmaxf(max3f(p_diag - g1, p_up2 - g2, p_left2 - g3), 0.0f);
+                    }
+                } else if (KIND == KIND_DMAX) {
+                    const float p_up3 = c >= 1 ? d3[c - 1] : h3a;                                   // D[i-3][j-1]
+                    const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));  // D[i-1][j-3]
+                    const float s_up1 = (float)seg_byte<NW>(s1, hs1, c);        // S[i-1][j]
+                    const float s_up2 = (float)seg_byte<NW>(s2, hs2, c);        // S[i-2][j]
+                    const float s_l1 = (float)seg_byte<NW>(s0, hs0, c - 1);     // S[i][j-1]
+                    const float s_l2 = (float)seg_byte<NW>(s0, hs0, c - 2);     // S[i][j-2]
+                    float c1 = p_diag;
+                    float c2 = p_up2 + s_up1;
+                    float c3 = p_left2 + s_l1;
+                    float c4 = (p_up3 + s_up2) + s_up1;
+                    float c5 = (p_left3 + s_l2) + s_l1;
+                    if (cur == 1u) {
+                        v = fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5) + 1.0f;
+                    } else {
+                        c1 -= seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                        c2 -= seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                        c3 -= seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
+                        c4 -= seg_byte<NW>(s3, hs3, c - 1) == 1u ? prm.g_on : prm.g_ext;
+                        c5 -= seg_byte<NW>(s1, hs1, c - 3) == 1u ? prm.g_on : prm.g_ext;
+                        v = fmaxf(fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5), 0.0f);
+                    }
+                } else {   // KIND_SWC, in mask coordinates (a, b) = (i, j), D cell (a+1, b+1)
+                    const float ms = cur == 0u ? prm.sw_mismatch : prm.sw_match;
+                    const unsigned q1 = seg_byte<NW>(s1, hs1, c - 1);   // S[a-1][b-1]
+                    const unsigned q2 = seg_byte<NW>(s2, hs2, c - 1);   // S[a-2][b-1]
+                    const unsigned q3 = seg_byte<NW>(s1, hs1, c - 2);   // S[a-1][b-2]
+                    const float e1 = cur > 0u ? 0.0f : (q1 > 0u ? prm.sw_open : prm.sw_ext);
+                    const float e2 = cur > 0u ? 0.0f : (q2 > 0u ? prm.sw_open : prm.sw_ext);
+                    const float e3 = cur > 0u ? 0.0f : (q3 > 0u ? prm.sw_open : prm.sw_ext);
+                    v = fmaxf(max3f((p_diag + ms) + e1, (p_up2 + ms) + e2, (p_left2 + ms) + e3), 0.0f);
                 }
-            } else if (KIND == KIND_DMAX) {
-                const float p_up3 = c >= 1 ? d3[c - 1] : h3a;                                   // D[i-3][j-1]
-                const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));  // D[i-1][j-3]
-                const float s_up1 = (float)seg_byte<NW>(s1, hs1, c);        // S[i-1][j]
-                const float s_up2 = (float)seg_byte<NW>(s2, hs2, c);        // S[i-2][j]
-                const float s_l1 = (float)seg_byte<NW>(s0, hs0, c - 1);     // S[i][j-1]
-                const float s_l2 = (float)seg_byte<NW>(s0, hs0, c - 2);     // S[i][j-2]
-                float c1 = p_diag;
-                float c2 = p_up2 + s_up1;
-                float c3 = p_left2 + s_l1;
-                float c4 = (p_up3 + s_up2) + s_up1;
-                float c5 = (p_left3 + s_l2) + s_l1;
-                if (cur == 1u) {
-                    v = fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5) + 1.0f;
-                } else {
-                    c1 -= seg_byte<NW>(s1, hs1, c - 1) == 1u ? prm.g_on : prm.g_ext;
-                    c2 -= seg_byte<NW>(s2, hs2, c - 1) == 1u ? prm.g_on : prm.g_ext;
-                    c3 -= seg_byte<NW>(s1, hs1, c - 2) == 1u ? prm.g_on : prm.g_ext;
-                    c4 -= seg_byte<NW>(s3, hs3, c - 1) == 1u ? prm.g_on : prm.g_ext;
-                    c5 -= seg_byte<NW>(s1, hs1, c - 3) == 1u ? prm.g_on : prm.g_ext;
-                    v = fmaxf(fmaxf(fmaxf(max3f(c1, c2, c3), c4), c5), 0.0f);
-                }
-            } else {   // KIND_SWC, in mask coordinates (a, b) = (i, j), D cell (a+1, b+1)
-                const float ms = cur == 0u ? prm.sw_mismatch : prm.sw_match;
-                const unsigned q1 = seg_byte<NW>(s1, hs1, c - 1);   // S[a-1][b-1]
-                const unsigned q2 = seg_byte<NW>(s2, hs2, c - 1);   // S[a-2][b-1]
-                const unsigned q3 = seg_byte<NW>(s1, hs1, c - 2);   // S[a-1][b-2]
-                const float e1 = cur > 0u ? 0.0f : (q1 > 0u ? prm.sw_open : prm.sw_ext);
-                const float e2 = cur > 0u ? 0.0f : (q2 > 0u ? prm.sw_open : prm.sw_ext);
-                const float e3 = cur > 0u ? 0.0f : (q3 > 0u ? prm.sw_open : prm.sw_ext);
-                v = fmaxf(max3f((p_diag + ms) + e1, (p_up2 + ms) + e2, (p_left2 + ms) + e3), 0.0f);
+                const bool valid = j >= FIRST && j < N;
+                nd[c] = valid ? v : 0.0f;
             }
-            const bool valid = j >= FIRST && j < N;
-            nd[c] = valid ? v : 0.0f;
-        }
-        // columns the recurrence never writes keep their boundary values
-        if (j0 < FIRST) {
+            // columns the recurrence never writes keep their boundary values
+            if (j0 < FIRST) {
 #pragma unroll
-            for (int c = 0; c < FIRST; c++) {
-                if (dbase) {
-                    nd[c] = dbase[(int64_t)i * md.d_pitch + c];
-                } else if (KIND == KIND_DMAX && prm.boundary && c == 2) {
-                    nd[c] = seg_byte<NW>(s0, 0, 2) == 1u ? 1.0f : 0.0f;   // qmax's D[i][2]
+                for (int c = 0; c < FIRST; c++) {
+                    if (dbase) {
+                        nd[c] = dbase[(int64_t)i * md.d_pitch + c];
+                    } else if (KIND == KIND_DMAX && prm.boundary && c == 2) {
+                        nd[c] = seg_byte<NW>(s0, 0, 2) == 1u ? 1.0f : 0.0f;   // qmax's D[i][2]
+                    }
                 }
             }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int j = j0 + c;
+                const bool valid = j >= FIRST && j < N;
+                if (valid) best = fmaxf(best, nd[c]);
+                if (dbase && valid) dbase[(int64_t)i * md.d_pitch + j] = nd[c];
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) { d3[c] = d2[c]; d2[c] = d1[c]; d1[c] = nd[c]; }
+#pragma unroll
+            for (int q = 0; q < NW; q++) { s3[q] = s2[q]; s2[q] = s1[q]; s1[q] = s0[q]; }
+    };
+    for (int ib = FIRST; ib < M; ib += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = ib + u;
+            if (i < M) {
+                unsigned s0[NW];
+#pragma unroll
+                for (int q = 0; q < NW; q++) s0[q] = ring[u][q];
+                if (i + PF < M) load_mask_row<NW>(sbase + (int64_t)(i + PF) * md.s_pitch, j0, N, aligned, ring[u]);
+                do_row(i, s0);
+            }
         }
-#pragma unroll
-        for (int c = 0; c < CPL; c++) {
-            const int j = j0 + c;
-            const bool valid = j >= FIRST && j < N;
-            if (valid) best = fmaxf(best, nd[c]);
-            if (dbase && valid) dbase[(int64_t)i * md.d_pitch + j] = nd[c];
-        }
-#pragma unroll
-        for (int c = 0; c < CPL; c++) { d3[c] = d2[c]; d2[c] = d1[c]; d1[c] = nd[c]; }
-#pragma unroll
-        for (int q = 0; q < NW; q++) { s3[q] = s2[q]; s2[q] = s1[q]; s1[q] = s0[q]; }
     }
     // wave max
 #pragma unroll

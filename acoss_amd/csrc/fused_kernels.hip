@@ -1,0 +1,351 @@
+// fused_kernels.hip -- the fast forms of the cross-similarity half of the path (gfx950):
+//
+//   pack_x_kernel        per pair, the x song's frames rotated by the OTI (Serra09.py:167) and
+//                        packed one frame per 128-byte line [d values | squared norm | zeros], so
+//                        that a kernel that walks x frames as its wave-uniform operand fetches a
+//                        whole frame with two scalar loads instead of d+1 rotated ones;
+//   csm_packed_kernel    get_csm (CRPUtils.py:67-84) on packed x: same tiling as csm_kernel;
+//   crp_kernel           get_csm + sliding_csm fused (CRPUtils.py:67-84 + :24-45): the windowed sums
+//                        of squared distances S^2[i][j] = sum_k C[i+k][j+k] (or their sqrt) straight
+//                        from the features; the CSM never touches HBM.
+#include "common.h"
+#include "kernel_utils.h"
+
+namespace acoss {
+
+constexpr int XP_STRIDE = 16;   // elements per packed frame (128 B for float64)
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_x_kernel(const T *__restrict__ feats, const T *__restrict__ norms,
+                                                     int d, const acoss_pair_desc *__restrict__ descs,
+                                                     int max_nx, int blocks_per_pair, T *__restrict__ xp)
+{
+    const int p = blockIdx.x / blocks_per_pair;
+    const acoss_pair_desc ds = descs[p];
+    const int f = (blockIdx.x % blocks_per_pair) * 16 + (threadIdx.x >> 4);
+    const int slot = threadIdx.x & 15;
+    if (f >= ds.nx) return;
+    T v = 0;
+    if (slot < d) {
+        int src = slot - ds.shift;   // X1[f][b] = X[f][(b - shift) mod d]
+        if (src < 0) src += d;
+        v = feats[(ds.x_row0 + f) * d + src];
+    } else if (slot == d) {
+        v = norms[ds.x_row0 + f];
+    }
+    xp[((int64_t)p * max_nx + f) * XP_STRIDE + slot] = v;
+}
+
+// ---------------------------------------------------------------------------------------------
+// CSM on packed x.  Identical arithmetic to csm_kernel (same FMA order over the rolled bins, same
+// norms), so the two agree bit for bit; only the x-frame fetch differs.
+// ---------------------------------------------------------------------------------------------
+constexpr int CSM_TM = 128, CSM_TN = 128, CSM_ROWS_PER_WAVE = 32;
+
+template <typename T, int D>
+__global__ __launch_bounds__(256) void csm_packed_kernel(const T *__restrict__ xp, int max_nx,
+                                                         const T *__restrict__ feats, const T *__restrict__ norms,
+                                                         const acoss_pair_desc *__restrict__ descs,
+                                                         int tiles_m, int tiles_n, T *__restrict__ out)
+{
+    static_assert(D < XP_STRIDE, "packed frame holds d values and the norm");
+    // the tile's 128 packed x frames: one coalesced 16-byte-per-lane sweep into LDS, then every
+    // wave reads the frame of its current row as LDS broadcasts (all lanes, same address)
+    __shared__ __attribute__((aligned(16))) T xs[CSM_TM * XP_STRIDE];
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int i0 = (t / tiles_n) * CSM_TM, j0 = (t % tiles_n) * CSM_TN;
+    if (i0 >= ds.nx || j0 >= ds.ny) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    {
+        constexpr int VEC = 16 / sizeof(T);                       // elements per 16-byte load
+        constexpr int CHUNKS = CSM_TM * XP_STRIDE / VEC;          // 16-byte chunks in the tile's x block
+        const T *xsrc = xp + ((int64_t)p * max_nx + i0) * XP_STRIDE;
+        const int valid_chunks = min(CSM_TM, ds.nx - i0) * XP_STRIDE / VEC;
+#pragma unroll
+        for (int c = threadIdx.x; c < CHUNKS; c += 256) {
+            const int cc = min(c, valid_chunks - 1);              // clamp: rows past the song are never used
+            reinterpret_cast<uint4 *>(xs)[c] = reinterpret_cast<const uint4 *>(xsrc)[cc];
+        }
+    }
+
+    const int j = j0 + 2 * lane;
+    const bool ok0 = j < ds.ny, ok1 = j + 1 < ds.ny;
+    const int ja = min(j, ds.ny - 1), jb = min(j + 1, ds.ny - 1);
+    T y0[D], y1[D];
+    {
+        const T *yp0 = feats + (ds.y_row0 + ja) * D;
+        const T *yp1 = feats + (ds.y_row0 + jb) * D;
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            y0[b] = yp0[b];
+            y1[b] = yp1[b];
+        }
+    }
+    const T yy0 = norms[ds.y_row0 + ja];
+    const T yy1 = norms[ds.y_row0 + jb];
+    __syncthreads();
+
+    T *orow = out + ds.csm_off + (int64_t)j;
+    const int r_begin = wave * CSM_ROWS_PER_WAVE;
+    const int r_end = min(r_begin + CSM_ROWS_PER_WAVE, ds.nx - i0);
+    const bool full = (j0 + CSM_TN <= ds.ny) && ((ds.csm_pitch & 1) == 0) && ((ds.csm_off & 1) == 0);
+#pragma unroll 4
+    for (int r = r_begin; r < r_end; r++) {
+        const T *xr = xs + r * XP_STRIDE;
+        T a0 = 0, a1 = 0;
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            a0 = fma(xr[b], y0[b], a0);
+            a1 = fma(xr[b], y1[b], a1);
+        }
+        const T c0 = csm_sqrt(fma((T)-2, a0, xr[D] + yy0));
+        const T c1 = csm_sqrt(fma((T)-2, a1, xr[D] + yy1));
+        T *dst = orow + (int64_t)(i0 + r) * ds.csm_pitch;
+        if (full) {   // wave-uniform
+            if constexpr (sizeof(T) == 8) {
+                *reinterpret_cast<double2 *>(dst) = make_double2(c0, c1);
+            } else {
+                *reinterpret_cast<float2 *>(dst) = make_float2(c0, c1);
+            }
+        } else {
+            if (ok0) dst[0] = c0;
+            if (ok1) dst[1] = c1;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused CSM + sliding window.
+//
+// Block = 4 waves.  Phase 1 computes a 32 x 128 tile of squared distances C (clamped at 0) into LDS
+// exactly like the CSM kernel does (lane = 2 columns with its y frames in VGPRs, x frame by scalar
+// loads from the packed line, 8 rows per wave); phase 2 forms the (32-w+1) x (128-w+1) outputs
+// sum_{k<w} C[r+k][c+k] with w lane-contiguous (conflict-free) 8-byte LDS reads each and streams them
+// out, 512 contiguous bytes per wave instruction.  For w = 9 a 24 x 120 output tile costs 1.42 x its
+// own size in C evaluations; nothing but the result is written to HBM.
+//   float64 features: sum of the clamped squared distances (the reference squares the square roots
+//                     again, CRPUtils.py:40 -- identical up to one rounding);
+//   float32 features: sqrtf, square in float32, promote, sum in float64 (CRPUtils.py:40-41 exactly).
+// ---------------------------------------------------------------------------------------------
+constexpr int CRP_RT = 32, CRP_CT = 128, CRP_LD = CRP_CT + 2;
+
+template <typename T, int D, int WIN, bool SQRT_OUT>
+__global__ __launch_bounds__(256) void crp_kernel(const T *__restrict__ xp, int max_nx,
+                                                  const T *__restrict__ feats, const T *__restrict__ norms,
+                                                  const acoss_pair_desc *__restrict__ descs, int win_rt,
+                                                  int tiles_m, int tiles_n, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double cl[CRP_RT * CRP_LD];
+    __shared__ __attribute__((aligned(16))) T xs[CRP_RT * XP_STRIDE];   // the tile's 32 packed x frames
+    const int win = WIN > 0 ? WIN : win_rt;
+    const int TM = CRP_RT - (win - 1), TN = CRP_CT - (win - 1);
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int i0 = (t / tiles_n) * TM, j0 = (t % tiles_n) * TN;
+    if (i0 >= M || j0 >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- phase 1: C tile -> LDS
+    {
+        constexpr int VEC = 16 / sizeof(T);
+        constexpr int CHUNKS = CRP_RT * XP_STRIDE / VEC;           // 256 (f64) / 128 (f32) 16-byte chunks
+        const T *xsrc = xp + ((int64_t)p * max_nx + i0) * XP_STRIDE;
+        const int valid_chunks = min(CRP_RT, ds.nx - i0) * XP_STRIDE / VEC;
+        if (threadIdx.x < CHUNKS)
+            reinterpret_cast<uint4 *>(xs)[threadIdx.x] =
+                reinterpret_cast<const uint4 *>(xsrc)[min((int)threadIdx.x, valid_chunks - 1)];
+    }
+    {
+        const int j = j0 + 2 * lane;
+        const int ja = min(j, ds.ny - 1), jb = min(j + 1, ds.ny - 1);   // clamped: out-of-range cells are never read back
+        T y0[D], y1[D];
+        const T *yp0 = feats + (ds.y_row0 + ja) * D;
+        const T *yp1 = feats + (ds.y_row0 + jb) * D;
+#pragma unroll
+        for (int b = 0; b < D; b++) {
+            y0[b] = yp0[b];
+            y1[b] = yp1[b];
+        }
+        const T yy0 = norms[ds.y_row0 + ja], yy1 = norms[ds.y_row0 + jb];
+        __syncthreads();
+#pragma unroll
+        for (int rr = wave * (CRP_RT / 4); rr < (wave + 1) * (CRP_RT / 4); rr++) {
+            const T *xr = xs + rr * XP_STRIDE;   // rows past the song hold a clamped copy: never read back
+            T a0 = 0, a1 = 0;
+#pragma unroll
+            for (int b = 0; b < D; b++) {
+                a0 = fma(xr[b], y0[b], a0);
+                a1 = fma(xr[b], y1[b], a1);
+            }
+            T c0 = fma((T)-2, a0, xr[D] + yy0);
+            T c1 = fma((T)-2, a1, xr[D] + yy1);
+            double q0, q1;
+            if constexpr (sizeof(T) == 8) {
+                q0 = fmax(c0, 0.0);
+                q1 = fmax(c1, 0.0);
+            } else {
+                const float r0 = sqrtf(fmaxf(c0, 0.0f)), r1 = sqrtf(fmaxf(c1, 0.0f));
+                q0 = (double)(r0 * r0);
+                q1 = (double)(r1 * r1);
+            }
+            *reinterpret_cast<double2 *>(&cl[rr * CRP_LD + 2 * lane]) = make_double2(q0, q1);
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: diagonal window sums
+    double *obase = out + ds.crp_off + j0;
+    const int ca = lane, cb = lane + 64;
+    const bool oka = ca < TN && j0 + ca < N, okb = cb < TN && j0 + cb < N;
+    for (int r = wave; r < TM; r += 4) {
+        const int gi = i0 + r;
+        if (gi >= M) break;
+        double sa = 0.0, sb = 0.0;
+        if (WIN > 0) {
+#pragma unroll
+            for (int k = 0; k < (WIN > 0 ? WIN : 1); k++) {
+                sa += cl[(r + k) * CRP_LD + ca + k];
+                sb += cl[(r + k) * CRP_LD + (okb ? cb : ca) + k];
+            }
+        } else {
+            for (int k = 0; k < win; k++) {
+                sa += cl[(r + k) * CRP_LD + ca + k];
+                sb += cl[(r + k) * CRP_LD + (okb ? cb : ca) + k];
+            }
+        }
+        if (SQRT_OUT) {
+            sa = csm_sqrt(sa);
+            sb = csm_sqrt(sb);
+        }
+        double *orow = obase + (int64_t)gi * ds.crp_pitch;
+        if (oka) orow[ca] = sa;
+        if (okb) orow[cb] = sb;
+    }
+}
+
+template <typename T>
+static int launch_pack(const T *feats, const T *norms, int d, const acoss_pair_desc *descs, int K, int max_nx,
+                       T *xp, hipStream_t st)
+{
+    if (!feats || !norms || !descs || !xp || K < 0 || d < 1 || d >= XP_STRIDE || max_nx < 1) {
+        set_error("pack_x: bad argument (1 <= d <= 15)");
+        return ACOSS_EINVAL;
+    }
+    if (K == 0) return ACOSS_OK;
+    const int bpp = ceil_div(max_nx, 16);
+    const int64_t blocks = (int64_t)K * bpp;
+    if (blocks > 0x7fffffffLL) { set_error("pack_x: batch too large"); return ACOSS_ENOTSUP; }
+    hipLaunchKernelGGL(pack_x_kernel<T>, dim3((unsigned)blocks), dim3(256), 0, st, feats, norms, d, descs, max_nx, bpp, xp);
+    return launch_check("pack_x_kernel");
+}
+
+template <typename T>
+static int launch_csm_packed(const T *xp, const T *feats, const T *norms, int d, const acoss_pair_desc *descs,
+                             int K, int max_nx, int max_ny, T *csm, hipStream_t st)
+{
+    if (!xp || !feats || !norms || !descs || !csm || K < 0 || max_nx < 1 || max_ny < 1) {
+        set_error("csm_packed_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if (d != 12 && d != 13) { set_error("csm_packed_batch: d must be 12 or 13 (use acoss_csm_batch for other sizes)"); return ACOSS_ENOTSUP; }
+    if (K == 0) return ACOSS_OK;
+    const int tm = ceil_div(max_nx, CSM_TM), tn = ceil_div(max_ny, CSM_TN);
+    const int64_t blocks = (int64_t)K * tm * tn;
+    if (blocks > 0x7fffffffLL) { set_error("csm_packed_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if (d == 12)
+        hipLaunchKernelGGL((csm_packed_kernel<T, 12>), dim3((unsigned)blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, tm, tn, csm);
+    else
+        hipLaunchKernelGGL((csm_packed_kernel<T, 13>), dim3((unsigned)blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, tm, tn, csm);
+    return launch_check("csm_packed_kernel");
+}
+
+template <typename T, int D>
+static void launch_crp_d(const T *xp, int max_nx, const T *feats, const T *norms, const acoss_pair_desc *descs,
+                         int win, int tm, int tn, unsigned blocks, int sqrt_out, double *out, hipStream_t st)
+{
+    if (win == 9) {
+        if (sqrt_out) hipLaunchKernelGGL((crp_kernel<T, D, 9, true>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+        else hipLaunchKernelGGL((crp_kernel<T, D, 9, false>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+    } else {
+        if (sqrt_out) hipLaunchKernelGGL((crp_kernel<T, D, 0, true>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+        else hipLaunchKernelGGL((crp_kernel<T, D, 0, false>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+    }
+}
+
+template <typename T>
+static int launch_crp(const T *xp, const T *feats, const T *norms, int d, const acoss_pair_desc *descs, int K,
+                      int win, int max_nx, int max_ny, int sqrt_out, double *out, hipStream_t st)
+{
+    if (!xp || !feats || !norms || !descs || !out || K < 0 || win < 1 || max_nx < win || max_ny < win) {
+        set_error("crp_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if ((d != 12 && d != 13) || win > 16) {
+        set_error("crp_batch: supports d in {12, 13} and win <= 16 (use csm_batch + sliding_batch otherwise)");
+        return ACOSS_ENOTSUP;
+    }
+    if (K == 0) return ACOSS_OK;
+    const int TM = CRP_RT - (win - 1), TN = CRP_CT - (win - 1);
+    const int tm = ceil_div(max_nx - win + 1, TM), tn = ceil_div(max_ny - win + 1, TN);
+    const int64_t blocks = (int64_t)K * tm * tn;
+    if (blocks > 0x7fffffffLL) { set_error("crp_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if (d == 12) launch_crp_d<T, 12>(xp, max_nx, feats, norms, descs, win, tm, tn, (unsigned)blocks, sqrt_out, out, st);
+    else launch_crp_d<T, 13>(xp, max_nx, feats, norms, descs, win, tm, tn, (unsigned)blocks, sqrt_out, out, st);
+    return launch_check("crp_kernel");
+}
+
+}  // namespace acoss
+
+using namespace acoss;
+
+extern "C" {
+
+int64_t acoss_xpack_elems(int K, int max_nx)
+{
+    return (int64_t)(K > 0 ? K : 0) * (int64_t)(max_nx > 0 ? max_nx : 0) * XP_STRIDE;
+}
+
+int acoss_pack_x_f64(const double *feats, const double *norms, int d, const acoss_pair_desc *descs, int K,
+                     int max_nx, double *xp, void *stream)
+{
+    return launch_pack<double>(feats, norms, d, descs, K, max_nx, xp, (hipStream_t)stream);
+}
+int acoss_pack_x_f32(const float *feats, const float *norms, int d, const acoss_pair_desc *descs, int K,
+                     int max_nx, float *xp, void *stream)
+{
+    return launch_pack<float>(feats, norms, d, descs, K, max_nx, xp, (hipStream_t)stream);
+}
+
+int acoss_csm_packed_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm, void *stream)
+{
+    return launch_csm_packed<double>(xp, feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float *norms, int d,
+                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, float *csm, void *stream)
+{
+    return launch_csm_packed<float>(xp, feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+
+int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                        const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
+                        double *out, void *stream)
+{
+    return launch_crp<double>(xp, feats, norms, d, descs, K, win, max_nx, max_ny, sqrt_out, out, (hipStream_t)stream);
+}
+int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms, int d,
+                        const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
+                        double *out, void *stream)
+{
+    return launch_crp<float>(xp, feats, norms, d, descs, K, win, max_nx, max_ny, sqrt_out, out, (hipStream_t)stream);
+}
+
+}  // extern "C"

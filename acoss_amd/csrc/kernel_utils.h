@@ -1,0 +1,43 @@
+// kernel_utils.h -- device helpers shared by the CRP kernels.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+
+namespace acoss {
+
+// ---------------------------------------------------------------------------------------------
+// XCD-aware block remap: hardware deals consecutive block ids round-robin over the 8 XCDs; this
+// maps them back so that logically consecutive blocks (tiles of one pair, which share the two
+// songs' feature rows) run on one XCD and hit its L2.  Bijective for any grid size.
+// ---------------------------------------------------------------------------------------------
+__device__ inline int xcd_remap(int b, int nblk)
+{
+    const int q = nblk >> 3, r = nblk & 7, xcd = b & 7, idx = b >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
+
+// sqrt(max(c, 0)) for the CSM epilogue.  float64: v_rsq_f64 seed, one Goldschmidt step and two
+// Newton corrections (the sequence the compiler's own sqrt uses, correctly rounded), but without
+// the per-element exponent rescaling and class tests: zero flows through the iteration exactly
+// (0 * finite seed), and the only inputs the fast form cannot take -- positive values below
+// 2^-900 -- are sent to the library sqrt by a wave-uniform branch that is never taken on real
+// features.
+__device__ inline double csm_sqrt(double c)
+{
+    c = fmax(c, 0.0);
+    const double tiny = 0x1.0p-900;
+    if (__builtin_expect(__any(c > 0.0 && c < tiny), 0)) return sqrt(c);
+    const double y = __builtin_amdgcn_rsq(fmax(c, tiny));
+    double g = c * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, c), h, g);
+    g = fma(fma(-g, g, c), h, g);
+    return g;
+}
+__device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
+
+
+}  // namespace acoss

@@ -65,101 +65,112 @@ __device__ inline double f64_from_key(uint64_t k)
 }
 
 // Result of a selection: mask rule is  (key < thr_key) || (key == thr_key && index <= cut).
+// Number of lanes of the wave for which `pred` holds: the compare writes its lane mask straight into
+// an SGPR pair and the scalar unit counts the bits, so a count costs one VALU instruction and no
+// cross-lane reduction.
+__device__ inline int wave_count(bool pred) { return __popcll(__ballot(pred)); }
+
 struct SelectResult {
     uint64_t thr_key;
     int cut;
 };
 
-// k-th smallest (1-based, 1 <= k <= n) of the n keys a wave holds in registers, EPL per lane,
-// element e of lane l having index e*64 + l (indices >= n hold UINT64_MAX and are never chosen).
-// Ties at the threshold are cut lowest-index first.  Wave-uniform result.
+// k-th smallest (1-based, 1 <= k <= n) of the n keys a wave holds in registers, EPL per lane.
+// idx[e] is the position (column or row number) of this lane's element e; elements with
+// idx >= n are padding (their key must be UINT64_MAX).  Ties at the threshold are cut
+// lowest-position first.  Wave-uniform result.
 //
-// Method: bit-serial search from the most significant bit, first over the high 32-bit words
-// (counts by v_cmp + v_addc per element and one DPP reduction per bit), then -- only if several
-// elements share the winning high word -- over the low words of those elements.
+// Method: bit-serial search from the most significant differing bit over the high 32-bit words:
+// per bit one v_cmp + v_addc per element and one DPP reduction (measured equal in time to the
+// ballot + s_bcnt1 form, at a third of the registers; the rare low-word / tie phases use ballots).  The search tracks how many
+// elements the current bucket [prefix, prefix + 2^b) still holds and stops as soon as it holds
+// exactly one -- on real data after ~log2(n) bits -- fetching that element with a masked wave
+// maximum.  Only if several elements share the whole high word does it continue over their low
+// words, and only if full keys are equal does it rank positions.
 template <int EPL>
-__device__ inline SelectResult wave_select_kth(const uint64_t (&key)[EPL], int n, int k)
+__device__ inline SelectResult wave_select_kth(const uint64_t (&key)[EPL], const int (&idx)[EPL], int n, int k)
 {
-    const int lane = threadIdx.x & 63;
     unsigned hi[EPL], lo[EPL];
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
         hi[e] = (unsigned)(key[e] >> 32);
         lo[e] = (unsigned)key[e];
     }
-    // common leading bits of the valid high words
     unsigned mn = 0xffffffffu, mx = 0u;
 #pragma unroll
     for (int e = 0; e < EPL; e++) {
-        const bool valid = e * 64 + lane < n;
+        const bool valid = idx[e] < n;
         mn = min(mn, valid ? hi[e] : 0xffffffffu);
         mx = max(mx, valid ? hi[e] : 0u);
     }
     mn = wave_umin(mn);
     mx = wave_umax(mx);
+    SelectResult res;
+    res.cut = 0x7fffffff;
     unsigned vh = mn;
+    int c_lo = 0, c_hi = n;          // elements below the bucket / below its end
+    int b = -1;
     if (mn != mx) {
-        const int top = 31 - __clz((int)(mn ^ mx));   // highest differing bit
+        const int top = 31 - __clz((int)(mn ^ mx));
         vh = (top == 31) ? 0u : (mn >> (top + 1)) << (top + 1);
-        for (int b = top; b >= 0; b--) {
+        for (b = top; b >= 0 && c_hi - c_lo > 1; b--) {
             const unsigned cand = vh | (1u << b);
             int c = 0;
 #pragma unroll
             for (int e = 0; e < EPL; e++) c += (hi[e] < cand) ? 1 : 0;
-            if (wave_sum(c) <= k - 1) vh = cand;
+            c = wave_sum(c);
+            if (c <= k - 1) { vh = cand; c_lo = c; } else { c_hi = c; }
         }
     }
-    // how many strictly below / equal in the high word
-    int cl = 0, ce = 0;
-#pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        cl += (hi[e] < vh) ? 1 : 0;
-        ce += (hi[e] == vh) ? 1 : 0;
-    }
-    cl = wave_sum(cl);
-    ce = wave_sum(ce);
-    unsigned vl = 0;
-    if (ce == 1) {
-        unsigned m = 0;
-#pragma unroll
-        for (int e = 0; e < EPL; e++) m = max(m, hi[e] == vh ? lo[e] : 0u);
-        vl = wave_umax(m);
-    } else {
-        const int k2 = k - cl;   // rank among the elements sharing the high word
-        for (int b = 31; b >= 0; b--) {
-            const unsigned cand = vl | (1u << b);
-            int c = 0;
-#pragma unroll
-            for (int e = 0; e < EPL; e++) c += (hi[e] == vh && lo[e] < cand) ? 1 : 0;
-            if (wave_sum(c) <= k2 - 1) vl = cand;
-        }
-    }
-    SelectResult res;
-    res.thr_key = ((uint64_t)vh << 32) | vl;
-    // ties: `need` of the elements equal to the threshold are taken, lowest index first
-    int below = 0, equal = 0;
-#pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        below += (key[e] < res.thr_key) ? 1 : 0;
-        equal += (key[e] == res.thr_key) ? 1 : 0;
-    }
-    below = wave_sum(below);
-    equal = wave_sum(equal);
-    int need = k - below;
-    res.cut = 0x7fffffff;
-    if (equal > need) {   // rare: exact ties across the cut
+    if (c_hi - c_lo == 1) {
+        // one element left in [vh, vh + 2^(b+1)): it is the k-th smallest
+        const unsigned span = (b + 1 >= 32) ? 0xffffffffu : ((1u << (b + 1)) - 1u);
+        unsigned mh = 0, ml = 0;
 #pragma unroll
         for (int e = 0; e < EPL; e++) {
-            unsigned long long m = __ballot(key[e] == res.thr_key);
-            const int c = __popcll(m);
-            if (need > 0 && need <= c) {
-                for (int t = 1; t < need; t++) m &= m - 1;   // drop the need-1 lowest set bits
-                res.cut = e * 64 + (__ffsll((long long)m) - 1);
-                need = 0;
-            } else if (need > 0) {
-                need -= c;
-            }
+            const bool in = (hi[e] - vh) <= span && idx[e] < n;
+            mh = max(mh, in ? hi[e] : 0u);
+            ml = max(ml, in ? lo[e] : 0u);
         }
+        res.thr_key = ((uint64_t)wave_umax(mh) << 32) | wave_umax(ml);
+        return res;
+    }
+    // several elements share the high word vh: rank k2 among them by the low word
+    const int k2 = k - c_lo;
+    int d_lo = 0, d_hi = c_hi - c_lo;
+    unsigned vl = 0;
+    for (b = 31; b >= 0 && d_hi - d_lo > 1; b--) {
+        const unsigned cand = vl | (1u << b);
+        int c = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) c += wave_count(hi[e] == vh && lo[e] < cand && idx[e] < n);
+        if (c <= k2 - 1) { vl = cand; d_lo = c; } else { d_hi = c; }
+    }
+    if (d_hi - d_lo == 1) {
+        const unsigned span = (b + 1 >= 32) ? 0xffffffffu : ((1u << (b + 1)) - 1u);
+        unsigned ml = 0;
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            const bool in = hi[e] == vh && (lo[e] - vl) <= span && idx[e] < n;
+            ml = max(ml, in ? lo[e] : 0u);
+        }
+        res.thr_key = ((uint64_t)vh << 32) | wave_umax(ml);
+        return res;
+    }
+    // exact ties: d_hi - d_lo elements equal (vh, vl); `need` of them are taken, lowest position first
+    res.thr_key = ((uint64_t)vh << 32) | vl;
+    const int equal = d_hi - d_lo, need = k2 - d_lo;
+    if (equal > need) {
+        // the need-th smallest position among the tied elements (bit-serial over positions)
+        int cut = 0;
+        for (int pb = 30; pb >= 0; pb--) {
+            const int cand = cut | (1 << pb);
+            int c = 0;
+#pragma unroll
+            for (int e = 0; e < EPL; e++) c += wave_count(key[e] == res.thr_key && idx[e] < cand && idx[e] < n);
+            if (c <= need - 1) cut = cand;
+        }
+        res.cut = cut;
     }
     return res;
 }

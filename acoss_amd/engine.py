@@ -147,6 +147,45 @@ def csm(corpus, batch, out=None):
     return out
 
 
+def pack_x(corpus, batch, out=None):
+    """Rotated, line-packed x frames of every pair (input of csm_packed / crp)."""
+    lib = _lib.load()
+    need = int(lib.acoss_xpack_elems(batch.K, batch.max_nx))
+    if out is None or out.numel() < need:
+        out = torch.empty(max(need, 1), dtype=corpus.feats.dtype, device=corpus.device)
+    fn = lib.acoss_pack_x_f64 if corpus.dtype == np.float64 else lib.acoss_pack_x_f32
+    check(fn(_ptr(corpus.feats), _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K, batch.max_nx,
+             _ptr(out), _stream()), "pack_x")
+    return out
+
+
+def csm_packed(corpus, batch, xp, out=None):
+    """CRPUtils.py:67 on packed x frames (same output as csm())."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(max(batch.total_csm, 1), dtype=corpus.feats.dtype, device=corpus.device)
+    fn = lib.acoss_csm_packed_batch_f64 if corpus.dtype == np.float64 else lib.acoss_csm_packed_batch_f32
+    check(fn(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K,
+             batch.max_nx, batch.max_ny, _ptr(out), _stream()), "csm_packed_batch")
+    return out
+
+
+def crp(corpus, batch, xp, sqrt_out=False, out=None):
+    """get_csm + sliding_csm fused (CRPUtils.py:67 + :24): windowed sums of squared distances
+    (sqrt_out=False) or their square roots = sliding_csm's output (sqrt_out=True); float64."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(max(batch.total_crp, 1), dtype=torch.float64, device=corpus.device)
+    fn = lib.acoss_crp_batch_f64 if corpus.dtype == np.float64 else lib.acoss_crp_batch_f32
+    check(fn(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K,
+             batch.win, batch.max_nx, batch.max_ny, int(bool(sqrt_out)), _ptr(out), _stream()), "crp_batch")
+    return out
+
+
+def crp_supported(corpus, win):
+    return corpus.d in (12, 13) and 1 <= win <= 16
+
+
 def sliding(csm_buf, batch, out=None):
     """CRPUtils.py:24 for every pair; float64 out."""
     lib = _lib.load()
@@ -200,8 +239,46 @@ def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None, mat
 
 
 # ---------------------------------------------------------------------------------------------
-# the Serra09 chain, staged (every intermediate materialised in HBM)
+# the Serra09 chain
 # ---------------------------------------------------------------------------------------------
+def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None):
+    """
+    Serra09.py:166-175 for every pair, fast path: oti -> pack_x -> crp (fused CSM + sliding window,
+    squared) -> mutual binarise -> qmax [-> dmax on qmax's boundary].  Falls back to the staged
+    chain for shapes the fused kernel does not cover.  Scores are divided by (M+N).
+    """
+    if not crp_supported(corpus, m):
+        return serra09_scores_staged(corpus, pairs, m, kappa, do_oti, want, batch_pairs)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    K = pairs.shape[0]
+    out = {k: np.zeros(K) for k in want}
+    if K == 0:
+        return out
+    if batch_pairs is None:
+        per_pair = float(corpus.lengths().max()) ** 2 * 9.2
+        batch_pairs = int(max(1, min(K, (8 << 30) // max(per_pair, 1.0))))
+    xp = T = B = work = None
+    for lo in range(0, K, batch_pairs):
+        sel = pairs[lo:lo + batch_pairs]
+        batch = PairBatch(corpus.frame_off, sel, m, corpus.device)
+        if do_oti:
+            oti(corpus, batch)
+        xp = pack_x(corpus, batch, out=xp)
+        if T is None or T.numel() < batch.total_crp:
+            T = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
+            B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
+        crp(corpus, batch, xp, sqrt_out=False, out=T)
+        binarize(T, batch, kappa, mutual=True, out=B, work=work)
+        mats, _ = batch.mats()
+        denom = (batch.M + batch.N).astype(np.float64)
+        if "qmax" in want:
+            out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats).cpu().numpy().astype(np.float64) / denom
+        if "dmax" in want:
+            out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
+    return out
+
+
+# every intermediate materialised in HBM, one kernel per reference function
 def serra09_scores_staged(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"),
                           batch_pairs=None, keep=None):
     """

@@ -13,9 +13,13 @@ the score vectors closes the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` describes the CSM kernel (the HBM-bound kernel the
-north star grades), timed live with HIP events on the launch stream inside the timed region;
-`cpu_baseline` is the CPU oracle's same chain timed on the host cores (rank 0, N=1 only).
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant HBM-bound kernel of the timed
+path -- the cross-similarity kernel: fused with the sliding window in the default fast path,
+materialising the CSM in `--path staged` -- timed live with HIP events on the launch stream inside
+the timed region (`stage_ms` has every stage).  `roofline_csm_materialising` is the stand-alone
+get_csm kernel on the same batch, measured outside the timed region.  `cpu_baseline` is the CPU
+oracle's same chain timed on the host cores (rank 0, N=1 only); `parity` says whether the GPU scores
+of the sampled pairs are identical to the oracle's.
 """
 import argparse
 import json
@@ -40,50 +44,73 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=2048)
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--path", choices=("staged",), default="staged")
+    ap.add_argument("--path", choices=("fast", "staged"), default="fast",
+                    help="fast: fused CSM+sliding kernel (the product path); staged: one kernel per reference function")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     return ap.parse_args()
 
 
-class StagedRunner(object):
-    """OTI -> CSM -> sliding -> binarise -> qmax through the stage kernels, all buffers
-    preallocated, every launch on torch's current stream."""
+STAGES = {"fast": ["oti", "pack_x", "crp", "binarize", "qmax"],
+          "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
 
-    def __init__(self, corpus, batches, m, kappa):
+
+class Runner(object):
+    """One step = OTI -> [fast: pack_x -> crp (fused CSM + sliding window) | staged: CSM -> sliding]
+    -> mutual kNN binarisation -> qmax.  All buffers are preallocated and every launch goes to
+    torch's current stream; HIP events between the stages give per-kernel times of the timed steps."""
+
+    def __init__(self, corpus, batches, m, kappa, path):
         import torch
         from acoss_amd import engine
-        self.engine, self.torch = engine, torch
+        self.engine, self.torch, self.path = engine, torch, path
         self.corpus, self.m, self.kappa = corpus, m, kappa
         dev = corpus.device
-        tc = max(b.total_csm for b in batches)
+        lib = engine._lib.load()
         tr = max(b.total_crp for b in batches)
-        self.C = torch.empty(tc, dtype=corpus.feats.dtype, device=dev)
         self.S = torch.empty(tr, dtype=torch.float64, device=dev)
         self.B = torch.zeros(tr, dtype=torch.uint8, device=dev)
-        need = max(int(engine._lib.load().acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
+        if path == "staged":
+            self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
+        else:
+            self.xp = torch.empty(max(int(lib.acoss_xpack_elems(b.K, b.max_nx)) for b in batches),
+                                  dtype=corpus.feats.dtype, device=dev)
+        need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
         self.work = torch.empty(need, dtype=torch.uint8, device=dev)
         self.plans = []
         for b in batches:
             mats, _ = b.mats()
             self.plans.append((b, mats, engine.to_device_bytes(mats, dev), int(mats["cols"].max())))
-        self.csm_bytes = [float(np.sum(corpus.feats.element_size() *
-                                       (b.descs["nx"].astype(np.float64) * b.descs["ny"] +
-                                        corpus.d * (b.descs["nx"].astype(np.float64) + b.descs["ny"]))))
-                          for b in batches]
+        es = corpus.feats.element_size()
+        nx = [b.descs["nx"].astype(np.float64) for b in batches]
+        ny = [b.descs["ny"].astype(np.float64) for b in batches]
+        # algorithmic bytes per launch of the cross-similarity kernel of each path (DESIGN.md section 4)
+        self.csm_bytes = [float(np.sum(es * (x * y + corpus.d * (x + y)))) for x, y in zip(nx, ny)]
+        self.crp_bytes = [float(np.sum(8.0 * (x - m + 1) * (y - m + 1) + es * corpus.d * (x + y))) for x, y in zip(nx, ny)]
 
     def step(self, i, scores_out, ev=None):
         e = self.engine
         b, mats, mats_dev, max_cols = self.plans[i]
+
+        def mark(k):
+            if ev is not None:
+                ev[k].record()
+        mark(0)
         e.oti(self.corpus, b)
-        if ev is not None:
-            ev[0].record()
-        e.csm(self.corpus, b, out=self.C)
-        if ev is not None:
-            ev[1].record()
-        e.sliding(self.C, b, out=self.S)
+        mark(1)
+        if self.path == "fast":
+            e.pack_x(self.corpus, b, out=self.xp)
+            mark(2)
+            e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)
+        else:
+            e.csm(self.corpus, b, out=self.C)
+            mark(2)
+            e.sliding(self.C, b, out=self.S)
+        mark(3)
         e.binarize(self.S, b, self.kappa, True, out=self.B, work=self.work)
+        mark(4)
         e.align("qmax", self.B, mats, mats_dev=mats_dev, max_cols=max_cols, scores=scores_out)
+        mark(5)
 
 
 def main():
@@ -112,9 +139,9 @@ def main():
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
     step_idx = [mine[(np.arange(P) + s * P) % len(mine)] for s in range(n_steps)]
     batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev) for ix in step_idx]
-    runner = StagedRunner(corpus, batches, m, kappa)
+    runner = Runner(corpus, batches, m, kappa, args.path)
     scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
-    events = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n_steps)]
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
 
     def barrier():
         if world > 1:
@@ -148,9 +175,17 @@ def main():
 
     total_pairs = world * args.steps * P
     value = total_pairs / elapsed
-    csm_ms = np.array([events[s][0].elapsed_time(events[s][1]) for s in range(args.warmup, n_steps)])
-    csm_bytes = float(np.mean(runner.csm_bytes[args.warmup:]))
-    achieved = csm_bytes / (float(np.mean(csm_ms)) * 1e-3) / 1e9
+    names = STAGES[args.path]
+    stage_ms = {names[k]: float(np.mean([events[s][k].elapsed_time(events[s][k + 1])
+                                          for s in range(args.warmup, n_steps)])) for k in range(5)}
+    # dominant HBM-bound kernel of the path: the cross-similarity kernel (fused with the sliding
+    # window in the fast path, materialising the CSM in the staged path)
+    if args.path == "fast":
+        kname, kms, kbytes = "crp_kernel<double,12,9> (CRPUtils.py:67 + :24 fused)", stage_ms["crp"], runner.crp_bytes
+    else:
+        kname, kms, kbytes = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
+    kbytes = float(np.mean(kbytes[args.warmup:]))
+    achieved = kbytes / (kms * 1e-3) / 1e9
 
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
@@ -163,16 +198,36 @@ def main():
                                % (args.songs, args.frames, P, len(all_pairs)),
                    "path": args.path, "pairs_per_step_per_gpu": P,
                    "parallelism": "pair-shard x%d, one all-gather" % world},
-        "roofline": {"kernel": "csm_kernel<double,12> (materialising CSM, CRPUtils.py:67)", "bound": "hbm",
+        "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                     "bytes_per_launch": csm_bytes, "avg_launch_ms": round(float(np.mean(csm_ms)), 4)},
+                     "bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 4)},
+        "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
+    if rank == 0 and args.path == "fast":
+        # the materialising CSM kernel (get_csm as an API, the kernel the north star names) on the
+        # same batch, outside the timed region: reported beside the path's own dominant kernel
+        C = torch.empty(batches[-1].total_csm, dtype=corpus.feats.dtype, device=dev)
+        ms = []
+        for _ in range(4):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            engine.csm(corpus, batches[-1], out=C)
+            e1.record()
+            torch.cuda.synchronize()
+            ms.append(e0.elapsed_time(e1))
+        cms = float(np.median(ms[1:]))
+        cb = runner.csm_bytes[-1]
+        out["roofline_csm_materialising"] = {"kernel": "csm_kernel<double,12> (CRPUtils.py:67), not on the fast path",
+                                             "bound": "hbm", "achieved": round(cb / cms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                                             "unit": "GB/s", "frac": round(cb / cms / 1e6 / HBM_PEAK_GBS, 4),
+                                             "bytes_per_launch": cb, "avg_launch_ms": round(cms, 4)}
+        del C
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         threads = max(1, min(os.cpu_count() or 1, 16))
-        n_cpu = args.cpu_pairs or 16 * threads
+        n_cpu = args.cpu_pairs or min(512 * threads, len(timed_idx))
         sample = all_pairs[timed_idx[:n_cpu]]
         oracle.serra09_pairs(corpus_h.feats, corpus_h.frame_off, corpus_h.gchroma, sample[:threads],
                              m=m, kappa=kappa, nthreads=threads, want_dmax=False)      # warm the scratch

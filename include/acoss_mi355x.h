@@ -150,6 +150,34 @@ int acoss_csm_batch_f32(const float *feats, const float *norms, int d,
                         const acoss_pair_desc *descs, int K, int max_nx, int max_ny,
                         float *csm, void *stream);
 
+/* Fast forms.  acoss_pack_x_* writes, per pair, the x song's frames rotated by descs[p].shift and
+ * packed one frame per 16-element line [d values | squared norm | zeros] into xp
+ * (acoss_xpack_elems(K, max_nx) elements, pair p at p*max_nx*16); 1 <= d <= 15.  The two consumers
+ * below then fetch an x frame with two scalar loads:
+ *   acoss_csm_packed_batch_*  = acoss_csm_batch_* (bit-identical output), d in {12, 13};
+ *   acoss_crp_batch_*         = get_csm followed by sliding_csm without the CSM ever reaching HBM:
+ *                               out[crp_off + i*crp_pitch + j] = sum_{k<win} C[i+k][j+k] when sqrt_out == 0
+ *                               (C = clamped squared distance; the square of what sliding_csm returns --
+ *                               the kNN selection only needs the order), or its sqrt when sqrt_out != 0.
+ *                               d in {12, 13}, win <= 16. */
+int64_t acoss_xpack_elems(int K, int max_nx);
+int acoss_pack_x_f64(const double *feats, const double *norms, int d, const acoss_pair_desc *descs, int K,
+                     int max_nx, double *xp, void *stream);
+int acoss_pack_x_f32(const float *feats, const float *norms, int d, const acoss_pair_desc *descs, int K,
+                     int max_nx, float *xp, void *stream);
+int acoss_csm_packed_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm,
+                               void *stream);
+int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float *norms, int d,
+                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, float *csm,
+                               void *stream);
+int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                        const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
+                        double *out, void *stream);
+int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms, int d,
+                        const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
+                        double *out, void *stream);
+
 /* CRPUtils.py:24-45 sliding_csm: S[i][j] = sqrt(sum_{k<win} csm[i+k][j+k]^2), always float64
  * out.  S is written at crp_off with pitch crp_pitch.  1 <= win <= 64. */
 int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,

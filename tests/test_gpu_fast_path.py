@@ -1,0 +1,90 @@
+"""GPU parity of the fast forms: packed-x CSM (bit-identical to the plain CSM kernel) and the fused
+CSM + sliding-window kernel, then the whole fast chain against the reference's scores."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from acoss_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _mat(buf, batch, p, what):
+    d = batch.descs[p]
+    if what == "csm":
+        rows, cols, off, pitch = d["nx"], d["ny"], d["csm_off"], d["csm_pitch"]
+    else:
+        rows, cols, off, pitch = d["nx"] - batch.win + 1, d["ny"] - batch.win + 1, d["crp_off"], d["crp_pitch"]
+    return buf[off:off + rows * pitch].cpu().numpy().reshape(rows, pitch)[:, :cols]
+
+
+@pytest.mark.parametrize("c", [0, 1, 2])
+def test_fused_kernels_against_reference_stages(eng, golden, c):
+    g = golden("stages")
+    p = "c%d_" % c
+    X, Y, m, kappa = g[p + "X"], g[p + "Y"], int(g[p + "m"]), float(g[p + "kappa"])
+    corpus = eng.DeviceCorpus(np.concatenate([X, Y]), np.array([0, len(X), len(X) + len(Y)]),
+                              gchroma=np.stack([g[p + "gX"], g[p + "gY"]]))
+    batch = eng.PairBatch(corpus.frame_off, [[0, 1]], m, corpus.device)
+    eng.oti(corpus, batch)
+    xp = eng.pack_x(corpus, batch)
+    C0 = eng.csm(corpus, batch)
+    C1 = eng.csm_packed(corpus, batch, xp)
+    assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C1, batch, 0, "csm"))     # same arithmetic, bit for bit
+    S = _mat(eng.crp(corpus, batch, xp, sqrt_out=True), batch, 0, "crp")
+    assert np.max(np.abs(S - g[p + "S"])) <= 1e-9
+    Tbuf = eng.crp(corpus, batch, xp, sqrt_out=False)
+    T = _mat(Tbuf, batch, 0, "crp")
+    assert np.max(np.abs(T - g[p + "S"] ** 2)) <= 1e-9
+    # selection on the squared sums gives the reference's masks
+    assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=False), batch, 0, "crp"), g[p + "B1"])
+    assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=True), batch, 0, "crp"), g[p + "B"])
+
+
+def test_fused_float32_features(eng, golden):
+    g = golden("stages")
+    X, Y = g["f32_X"], g["f32_Y"]
+    corpus = eng.DeviceCorpus(np.concatenate([X, Y]), np.array([0, len(X), len(X) + len(Y)]))
+    assert corpus.dtype == np.float32
+    batch = eng.PairBatch(corpus.frame_off, [[0, 1]], 9, corpus.device)
+    xp = eng.pack_x(corpus, batch)
+    assert np.array_equal(_mat(eng.csm(corpus, batch), batch, 0, "csm"), _mat(eng.csm_packed(corpus, batch, xp), batch, 0, "csm"))
+    S = _mat(eng.crp(corpus, batch, xp, sqrt_out=True), batch, 0, "crp")
+    assert np.max(np.abs(S - g["f32_S"])) <= 2e-6          # the CSM itself is float32 (2e-6 to the reference's BLAS)
+    # against our own staged float32 chain the fused kernel is exact
+    S2 = _mat(eng.sliding(eng.csm(corpus, batch), batch), batch, 0, "crp")
+    assert np.max(np.abs(S - S2)) <= 1e-15
+
+
+def test_fast_chain_scores(eng, golden, orc):
+    g = golden("serra09_mini")
+    corpus = eng.DeviceCorpus(g["feats"], g["frame_off"], gchroma=g["gchroma"])
+    res = eng.serra09_scores(corpus, g["pairs"], batch_pairs=30)
+    assert np.array_equal(res["qmax"], g["chroma_qmax"]) and np.array_equal(res["dmax"], g["chroma_dmax"])
+    mf = eng.DeviceCorpus(g["mfcc"], g["frame_off"])
+    res = eng.serra09_scores(mf, g["pairs"], do_oti=False)
+    assert np.array_equal(res["qmax"], g["mfcc_qmax"]) and np.array_equal(res["dmax"], g["mfcc_dmax"])
+    g = golden("pairs_1000")
+    corpus = eng.DeviceCorpus(g["feats"], g["frame_off"], gchroma=g["gchroma"])
+    res = eng.serra09_scores(corpus, g["pairs"])
+    assert np.array_equal(res["qmax"], g["chroma_qmax"]) and np.array_equal(res["dmax"], g["chroma_dmax"])
+
+
+def test_fast_chain_ragged_and_other_windows(eng, orc):
+    from acoss_amd import synth
+    lens = iter([9, 10, 12, 33, 64, 65, 100, 131, 257, 300])
+    ch = synth.make_corpus(5, 2, seed=79, lengths=lambda r: next(lens))
+    corpus = eng.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = np.array([(i, j) for i in range(10) for j in range(10)], dtype=np.int32)
+    res = eng.serra09_scores(corpus, pairs)
+    q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=4)
+    assert np.array_equal(res["qmax"], q) and np.array_equal(res["dmax"], d)
+    for m, kappa in ((1, 0.2), (4, 0.1), (16, 0.15)):      # window sizes other than the templated 9
+        sel = pairs[(pairs[:, 0] >= 3) & (pairs[:, 1] >= 3)]
+        res = eng.serra09_scores(corpus, sel, m=m, kappa=kappa)
+        q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, sel, m=m, kappa=kappa, nthreads=4)
+        assert np.array_equal(res["qmax"], q) and np.array_equal(res["dmax"], d), m

@@ -2,7 +2,7 @@
 import ctypes, sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth, _lib
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 ch = synth.make_corpus(16, 4, n_frames=1000, seed=20260)

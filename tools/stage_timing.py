@@ -5,7 +5,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, ".")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth
 
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 128
@@ -43,6 +43,18 @@ _, t = timed("qmax", lambda: engine.align("qmax", B, mats)); tot += t
 _, t2 = timed("dmax", lambda: engine.align("dmax", B, mats, boundary=1))
 _, t3 = timed("swc", lambda: engine.align("swc", B, mats))
 print("chain (oti+csm+sliding+binarize+qmax): %.3f ms for %d pairs -> %.0f pair-scores/s" % (tot, K, K / (tot * 1e-3)))
+# fast forms
+xp, t = timed("pack_x", lambda: engine.pack_x(corpus, batch)); tf = t
+_, t = timed("csm_packed_f64", lambda: engine.csm_packed(corpus, batch, xp, out=C))
+print("   csm_packed: %.1f GB/s algorithmic" % (K * 8.192e6 / (t * 1e-3) / 1e9))
+Tb = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
+_, t = timed("crp (squared)", lambda: engine.crp(corpus, batch, xp, False, out=Tb)); tf += t
+print("   crp: %.1f GB/s of output (7.87 MB/pair)" % (K * 7.872e6 / (t * 1e-3) / 1e9))
+_, t2 = timed("crp (sqrt)", lambda: engine.crp(corpus, batch, xp, True, out=Tb))
+engine.crp(corpus, batch, xp, False, out=Tb)
+_, t = timed("binarize(T)", lambda: engine.binarize(Tb, batch, 0.095, True, out=Bout, work=work)); tf += t
+_, t = timed("qmax", lambda: engine.align("qmax", Bout, mats)); tf += t
+print("fast chain (oti+pack+crp+binarize+qmax): %.3f ms for %d pairs -> %.0f pair-scores/s" % (tf + 0.03, K, K / ((tf + 0.03) * 1e-3)))
 # f32 csm
 c32 = engine.DeviceCorpus(corpus_h.feats.astype(np.float32), corpus_h.frame_off, gchroma=corpus_h.gchroma)
 _, t = timed("csm_f32", lambda: engine.csm(c32, batch))
