@@ -11,6 +11,9 @@
 #include "common.h"
 #include "kernel_utils.h"
 
+#include <type_traits>
+
+
 namespace acoss {
 
 constexpr int XP_STRIDE = 16;   // elements per packed frame (128 B for float64)
@@ -231,6 +234,308 @@ __global__ __launch_bounds__(256) void crp_kernel(const T *__restrict__ xp, int 
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Fused CSM + sliding window, float64, phase 1 on the matrix cores.
+//
+// The K = d contraction x_i . y_j of the 32 x 128 C tile runs as v_mfma_f64_16x16x4_f64 (the f64
+// matrix pipe has the same peak as the f64 VALU but is a separate pipe, so the VALU is left with the
+// epilogue and the window sums): each wave owns two 16-column blocks x two 16-row blocks = four
+// 16x16 accumulators, ceil(d/4) MFMAs each.  A fragments come from the LDS copy of the packed x
+// frames (row stride 18 doubles: conflict-free for the 16-rows x 4-bins fragment read), B fragments
+// straight from the y frames in global memory (bins >= d are fed as zeros, which also cancels the
+// norm slot of the packed line).  The accumulator layout (lane = column, 4 rows per register set)
+// writes to the LDS C tile as four 128-byte row segments per instruction.
+// ---------------------------------------------------------------------------------------------
+typedef double v4f64 __attribute__((ext_vector_type(4)));
+constexpr int XS_LD = 18;
+
+template <int D, int WIN, bool SQRT_OUT>
+__global__ __launch_bounds__(256) void crp_mfma_kernel(const double *__restrict__ xp, int max_nx,
+                                                       const double *__restrict__ feats, const double *__restrict__ norms,
+                                                       const acoss_pair_desc *__restrict__ descs, int win_rt,
+                                                       int tiles_m, int tiles_n, double *__restrict__ out)
+{
+    __shared__ __attribute__((aligned(16))) double cl[CRP_RT * CRP_LD];
+    __shared__ __attribute__((aligned(16))) double xs[CRP_RT * XS_LD];
+    constexpr int KSTEPS = (D + 3) / 4;
+    const int win = WIN > 0 ? WIN : win_rt;
+    const int TM = CRP_RT - (win - 1), TN = CRP_CT - (win - 1);
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int i0 = (t / tiles_n) * TM, j0 = (t % tiles_n) * TN;
+    if (i0 >= M || j0 >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+
+    // ---- packed x frames of the tile -> LDS (one 16-byte chunk per thread)
+    {
+        const double *xsrc = xp + ((int64_t)p * max_nx + i0) * XP_STRIDE;
+        const int valid_chunks = min(CRP_RT, ds.nx - i0) * (XP_STRIDE / 2);
+        const int c = min((int)threadIdx.x, valid_chunks - 1);
+        const double2 v = reinterpret_cast<const double2 *>(xsrc)[c];
+        *reinterpret_cast<double2 *>(&xs[(threadIdx.x >> 3) * XS_LD + (threadIdx.x & 7) * 2]) = v;
+    }
+    // ---- B fragments and column norms from the y frames
+    const int lr = lane & 15, lk = lane >> 4;
+    double bfrag[2][KSTEPS], yy[2];
+#pragma unroll
+    for (int cbi = 0; cbi < 2; cbi++) {
+        const int jc = min(j0 + 16 * (2 * wave + cbi) + lr, ds.ny - 1);
+        const double *yp = feats + (ds.y_row0 + jc) * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            const int bin = 4 * s + lk;
+            bfrag[cbi][s] = bin < D ? yp[min(bin, D - 1)] : 0.0;
+        }
+        yy[cbi] = norms[ds.y_row0 + jc];
+    }
+    __syncthreads();
+    // ---- phase 1: C tile by MFMA -> LDS
+    {
+        v4f64 acc[2][2];
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++)
+#pragma unroll
+            for (int cbi = 0; cbi < 2; cbi++) acc[rb][cbi] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+                const double a = xs[(16 * rb + lr) * XS_LD + 4 * s + lk];
+#pragma unroll
+                for (int cbi = 0; cbi < 2; cbi++)
+                    acc[rb][cbi] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[cbi][s], acc[rb][cbi], 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int row = 16 * rb + lk + 4 * r;
+                const double xx = xs[row * XS_LD + D];
+#pragma unroll
+                for (int cbi = 0; cbi < 2; cbi++) {
+                    const double c = fma(-2.0, acc[rb][cbi][r], xx + yy[cbi]);
+                    cl[row * CRP_LD + 16 * (2 * wave + cbi) + lr] = fmax(c, 0.0);
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: diagonal window sums
+    double *obase = out + ds.crp_off + j0;
+    const int ca = lane, cb = lane + 64;
+    const bool oka = ca < TN && j0 + ca < N, okb = cb < TN && j0 + cb < N;
+    for (int r = wave; r < TM; r += 4) {
+        const int gi = i0 + r;
+        if (gi >= M) break;
+        double sa = 0.0, sb = 0.0;
+        if (WIN > 0) {
+#pragma unroll
+            for (int k = 0; k < (WIN > 0 ? WIN : 1); k++) {
+                sa += cl[(r + k) * CRP_LD + ca + k];
+                sb += cl[(r + k) * CRP_LD + (okb ? cb : ca) + k];
+            }
+        } else {
+            for (int k = 0; k < win; k++) {
+                sa += cl[(r + k) * CRP_LD + ca + k];
+                sb += cl[(r + k) * CRP_LD + (okb ? cb : ca) + k];
+            }
+        }
+        if (SQRT_OUT) {
+            sa = csm_sqrt(sa);
+            sb = csm_sqrt(sb);
+        }
+        double *orow = obase + (int64_t)gi * ds.crp_pitch;
+        if (oka) orow[ca] = sa;
+        if (okb) orow[cb] = sb;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fused CSM + sliding window, float64, persistent column strips (the product kernel).
+//
+// One 8-wave block owns a strip of (128 - w + 1) output columns of one pair and walks DOWN it in
+// steps of 32 rows:
+//   * its y fragments (wave v = columns 16v..16v+15 of the 128-wide C strip) and column norms are
+//     loaded once;
+//   * the 32 packed x frames of step t+1 are fetched (one 16-byte chunk per thread) while step t is
+//     computed, and dropped into the other half of a double-buffered LDS slot;
+//   * step t computes C rows [32t, 32t+32) on the matrix cores into a ring of 32 + w - 1 LDS rows and
+//     then writes the window sums of output rows [32t - w + 1, 32t + 33 - w): every C row is computed
+//     exactly once per strip (no row halo), and the only global traffic besides the x/y frames is the
+//     result, 512 contiguous bytes per wave instruction.
+// Two barriers per step separate ring writes from ring reads.
+// ---------------------------------------------------------------------------------------------
+constexpr int STRIP_ROWS = 32;
+
+// MODE (development probes, product = 0): 1 = no result stores, 2 = no window sums (store a C value),
+// 3 = no MFMA phase (stale LDS contents summed)
+template <int D, int WIN, bool SQRT_OUT, int MODE = 0>
+__global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
+                                                        const double *__restrict__ feats, const double *__restrict__ norms,
+                                                        const acoss_pair_desc *__restrict__ descs, int strips,
+                                                        double *__restrict__ out)
+{
+    // C rows of the current step live in rows [HALO, HALO + 32) of `cbuf`; rows [0, HALO) hold the last
+    // HALO rows of the previous step (copied through registers across the step boundary), so every LDS
+    // address in the window sums is (a per-wave base) + (a compile-time offset): no ring arithmetic.
+    constexpr int HALO = WIN - 1;
+    constexpr int CROWS = STRIP_ROWS + HALO;
+    constexpr int TN = CRP_CT - HALO;
+    constexpr int KSTEPS = (D + 3) / 4;
+    constexpr int ROWS_PER_WAVE = STRIP_ROWS / 8;
+    __shared__ __attribute__((aligned(16))) double cbuf[CROWS * CRP_LD];
+    __shared__ __attribute__((aligned(16))) double xs[STRIP_ROWS * XS_LD];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / strips;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - WIN + 1, N = ds.ny - WIN + 1;
+    const int j0 = (lb % strips) * TN;
+    if (j0 >= N) return;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // 0..7
+    const int lr = lane & 15, lk = lane >> 4;
+    const int n_steps = (ds.nx + STRIP_ROWS - 1) / STRIP_ROWS;
+    const double *xsrc = xp + (int64_t)p * max_nx * XP_STRIDE;
+    const int last_chunk = ds.nx * (XP_STRIDE / 2) - 1;                  // 16-byte chunks of valid frames
+
+    // y fragments of this wave's 16 columns (kept for the whole strip)
+    double bfrag[KSTEPS], yy;
+    {
+        const int jc = min(j0 + 16 * wave + lr, ds.ny - 1);
+        const double *yp = feats + (ds.y_row0 + jc) * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            const int bin = 4 * s + lk;
+            bfrag[s] = bin < D ? yp[min(bin, D - 1)] : 0.0;
+        }
+        yy = norms[ds.y_row0 + jc];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) settle(bfrag[s]);
+        settle(yy);
+    }
+    // x frames of step 0 (threads 0..255: one 16-byte chunk each)
+    const bool loader = threadIdx.x < STRIP_ROWS * (XP_STRIDE / 2);
+    double *xs_dst = &xs[(threadIdx.x >> 3) * XS_LD + (threadIdx.x & 7) * 2];
+    if (loader)
+        *reinterpret_cast<double2 *>(xs_dst) = reinterpret_cast<const double2 *>(xsrc)[min((int)threadIdx.x, last_chunk)];
+    __syncthreads();
+
+    const int ca = lane, cb = lane + 64;
+    const bool oka = ca < TN && j0 + ca < N, okb = cb < TN && j0 + cb < N;
+    const int cbr = okb ? cb : ca;
+    // per-lane read bases of this wave's ROWS_PER_WAVE output rows, and write base of its 16 C columns
+    const double *rda = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + ca;
+    const double *rdb = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + cbr;
+    double *wr = cbuf + (HALO + lk) * CRP_LD + 16 * wave + lr;
+    // halo copy: thread h < HALO*128 moves element h of rows [32, 32+HALO) to rows [0, HALO)
+    const bool copier = threadIdx.x < HALO * (CRP_CT / 2);
+    const int hrow = (2 * threadIdx.x) / CRP_CT, hcol = (2 * threadIdx.x) % CRP_CT;
+    double *halo_src = cbuf + (STRIP_ROWS + (copier ? hrow : 0)) * CRP_LD + hcol;
+    double *halo_dst = cbuf + (copier ? hrow : 0) * CRP_LD + hcol;
+    double *orow = out + ds.crp_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * ds.crp_pitch;
+
+    // x frames are fetched two steps ahead (registers), so their HBM latency spans a whole step
+    double2 xn1 = make_double2(0.0, 0.0), xn2 = make_double2(0.0, 0.0);
+    if (loader && n_steps > 1)
+        xn1 = reinterpret_cast<const double2 *>(xsrc)[min(STRIP_ROWS * (XP_STRIDE / 2) + (int)threadIdx.x, last_chunk)];
+
+    // One step.  CHECKED = false is the interior form: every output row and column of the step exists,
+    // so each wave issues exactly 2 * ROWS_PER_WAVE unconditional stores -- a static count the compiler
+    // can put in its vmcnt waits, which keeps the x prefetch and the result stores in flight across
+    // steps (with data-dependent store counts it falls back to vmcnt(0): a full HBM round trip per step).
+    auto step = [&](const int t, auto checked_tag) {
+        constexpr bool CHECKED = decltype(checked_tag)::value;
+        const bool more = t + 1 < n_steps;
+        if (loader && t + 2 < n_steps)
+            xn2 = reinterpret_cast<const double2 *>(xsrc)[min((t + 2) * STRIP_ROWS * (XP_STRIDE / 2) + (int)threadIdx.x, last_chunk)];
+        // ---- C rows [32t, 32t+32) of this wave's 16 columns -> cbuf rows [HALO, HALO+32)
+        if (MODE != 3) {
+            v4f64 acc[2];
+            acc[0] = (v4f64){0.0, 0.0, 0.0, 0.0};
+            acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int s = 0; s < KSTEPS; s++) {
+#pragma unroll
+                for (int rb = 0; rb < 2; rb++) {
+                    const double a = xs[(16 * rb + lr) * XS_LD + 4 * s + lk];
+                    acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[s], acc[rb], 0, 0, 0);
+                }
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const double c = fma(-2.0, acc[rb][r], xs[(16 * rb + lk + 4 * r) * XS_LD + D] + yy);
+                    wr[(16 * rb + 4 * r) * CRP_LD] = fmax(c, 0.0);
+                }
+            }
+        }
+        lds_barrier();
+        // next step's x frames may now replace the current ones (nobody reads xs until the next step)
+        if (loader && more) *reinterpret_cast<double2 *>(xs_dst) = xn1;
+        xn1 = xn2;
+        // ---- output rows [32t - HALO, 32t + 32 - HALO): ROWS_PER_WAVE per wave, window sums from LDS
+        const int g0 = t * STRIP_ROWS - HALO + wave * ROWS_PER_WAVE;          // wave-uniform
+#pragma unroll
+        for (int q = 0; q < ROWS_PER_WAVE; q++) {
+            const int gi = g0 + q;
+            if (!CHECKED || (gi >= 0 && gi < M)) {
+                double sa = 0.0, sb = 0.0;
+                if (MODE == 2) {
+                    sa = rda[q * CRP_LD];
+                    sb = rdb[q * CRP_LD];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < WIN; k++) {
+                        sa += rda[(q + k) * CRP_LD + k];
+                        sb += rdb[(q + k) * CRP_LD + k];
+                    }
+                }
+                if (SQRT_OUT) {
+                    sa = csm_sqrt(sa);
+                    sb = csm_sqrt(sb);
+                }
+                double *o = orow + (int64_t)(t * STRIP_ROWS + q) * ds.crp_pitch;
+                if (MODE == 1) {
+                    if (sa == -1.25) o[ca] = sb;
+                } else if (CHECKED) {
+                    if (oka) o[ca] = sa;
+                    if (okb) o[cb] = sb;
+                } else {
+                    // pair up adjacent columns across neighbouring lanes (one DPP swap) so that every lane
+                    // issues ONE 16-byte store: even lanes write columns (l, l+1), odd lanes (63+l, 64+l)
+                    const bool odd = lane & 1;
+                    const double give = odd ? sa : sb;
+                    const int glo = __builtin_amdgcn_update_dpp(0, __double2loint(give), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                    const int ghi = __builtin_amdgcn_update_dpp(0, __double2hiint(give), 0xB1, 0xf, 0xf, true);
+                    const double got = __hiloint2double(ghi, glo);
+                    const double2 v = odd ? make_double2(got, sb) : make_double2(sa, got);
+                    const int col = odd ? 63 + lane : lane;
+                    if (col + 1 < TN) *reinterpret_cast<double2 *>(o + col) = v;
+                }
+            }
+        }
+        // carry the last HALO C rows over to the next step: read before the barrier, write after it
+        double2 hv = make_double2(0.0, 0.0);
+        if (copier) hv = *reinterpret_cast<const double2 *>(halo_src);
+        lds_barrier();
+        if (copier) *reinterpret_cast<double2 *>(halo_dst) = hv;
+    };
+    const bool full_strip = j0 + TN <= N;                     // block-uniform
+    step(0, std::true_type{});
+    if (full_strip) {
+        for (int t = 1; t < n_steps - 1; t++) step(t, std::false_type{});
+    } else {
+        for (int t = 1; t < n_steps - 1; t++) step(t, std::true_type{});
+    }
+    if (n_steps > 1) step(n_steps - 1, std::true_type{});
+}
+
 template <typename T>
 static int launch_pack(const T *feats, const T *norms, int d, const acoss_pair_desc *descs, int K, int max_nx,
                        T *xp, hipStream_t st)
@@ -267,10 +572,43 @@ static int launch_csm_packed(const T *xp, const T *feats, const T *norms, int d,
     return launch_check("csm_packed_kernel");
 }
 
+template <int D, int WIN>
+static void launch_crp_strip(const double *xp, int max_nx, const double *feats, const double *norms,
+                             const acoss_pair_desc *descs, int K, int max_ny, int sqrt_out, double *out, hipStream_t st)
+{
+    const int strips = ceil_div(max_ny - WIN + 1, CRP_CT - (WIN - 1));
+    const unsigned blocks = (unsigned)((int64_t)K * strips);
+    if (sqrt_out) hipLaunchKernelGGL((crp_strip_kernel<D, WIN, true>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else hipLaunchKernelGGL((crp_strip_kernel<D, WIN, false>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+}
+
+template <int D>
+static void launch_crp_mfma(const double *xp, int max_nx, const double *feats, const double *norms,
+                            const acoss_pair_desc *descs, int win, int tm, int tn, unsigned blocks, int sqrt_out,
+                            double *out, hipStream_t st)
+{
+    if (win == 9) {
+        if (sqrt_out) hipLaunchKernelGGL((crp_mfma_kernel<D, 9, true>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+        else hipLaunchKernelGGL((crp_mfma_kernel<D, 9, false>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+    } else {
+        if (sqrt_out) hipLaunchKernelGGL((crp_mfma_kernel<D, 0, true>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+        else hipLaunchKernelGGL((crp_mfma_kernel<D, 0, false>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
+    }
+}
+
 template <typename T, int D>
 static void launch_crp_d(const T *xp, int max_nx, const T *feats, const T *norms, const acoss_pair_desc *descs,
                          int win, int tm, int tn, unsigned blocks, int sqrt_out, double *out, hipStream_t st)
 {
+    // flags: bit 0 = write sqrt of the sums, bit 1 = force the VALU form of the float64 kernel
+    const bool force_valu = (sqrt_out & 2) != 0;
+    sqrt_out &= 1;
+    if constexpr (sizeof(T) == 8) {
+        if (!force_valu) {
+            launch_crp_mfma<D>(xp, max_nx, feats, norms, descs, win, tm, tn, blocks, sqrt_out, out, st);
+            return;
+        }
+    }
     if (win == 9) {
         if (sqrt_out) hipLaunchKernelGGL((crp_kernel<T, D, 9, true>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
         else hipLaunchKernelGGL((crp_kernel<T, D, 9, false>), dim3(blocks), dim3(256), 0, st, xp, max_nx, feats, norms, descs, win, tm, tn, out);
@@ -297,6 +635,16 @@ static int launch_crp(const T *xp, const T *feats, const T *norms, int d, const 
     const int tm = ceil_div(max_nx - win + 1, TM), tn = ceil_div(max_ny - win + 1, TN);
     const int64_t blocks = (int64_t)K * tm * tn;
     if (blocks > 0x7fffffffLL) { set_error("crp_batch: batch too large"); return ACOSS_ENOTSUP; }
+    // flags: bit 0 = sqrt, bit 1 = all-VALU tile kernel, bit 2 = matrix-core tile kernel;
+    // default for float64 and the window of the paper (m = 9): the persistent strip kernel
+    if constexpr (sizeof(T) == 8) {
+        if (win == 9 && (sqrt_out & 6) == 0) {
+            if (d == 12) launch_crp_strip<12, 9>(xp, max_nx, feats, norms, descs, K, max_ny, sqrt_out & 1, out, st);
+            else launch_crp_strip<13, 9>(xp, max_nx, feats, norms, descs, K, max_ny, sqrt_out & 1, out, st);
+            return launch_check("crp_strip_kernel");
+        }
+    }
+    sqrt_out &= 3;
     if (d == 12) launch_crp_d<T, 12>(xp, max_nx, feats, norms, descs, win, tm, tn, (unsigned)blocks, sqrt_out, out, st);
     else launch_crp_d<T, 13>(xp, max_nx, feats, norms, descs, win, tm, tn, (unsigned)blocks, sqrt_out, out, st);
     return launch_check("crp_kernel");
@@ -307,6 +655,20 @@ static int launch_crp(const T *xp, const T *feats, const T *norms, int d, const 
 using namespace acoss;
 
 extern "C" {
+
+// development probe (not part of the public ABI): strip kernel in a probe MODE
+int acoss_dev_crp_probe(int mode, const double *xp, const double *feats, const double *norms,
+                        const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *out, void *stream)
+{
+    const int strips = ceil_div(max_ny - 9 + 1, CRP_CT - 8);
+    const unsigned blocks = (unsigned)((int64_t)K * strips);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 1) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 1>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else if (mode == 2) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 2>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else if (mode == 3) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 3>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 0>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    return launch_check("crp_strip probe");
+}
 
 int64_t acoss_xpack_elems(int K, int max_nx)
 {

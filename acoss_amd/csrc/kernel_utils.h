@@ -17,6 +17,23 @@ __device__ inline int xcd_remap(int b, int nblk)
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the vector-memory
+// counter (s_waitcnt vmcnt(0)), i.e. it waits for every outstanding global store and prefetch of the
+// wave -- a full HBM round trip per barrier in a kernel that streams results out while it iterates.
+// Use this where the data exchanged across the barrier lives in LDS and global results are never
+// read back by the block.
+__device__ inline void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Pin the completion of an earlier global load HERE.  hipcc places the s_waitcnt vmcnt(N) of a load at
+// its first use; if that use sits inside a loop that also issues stores or prefetches, the counted wait
+// is re-executed every iteration and -- the counter being in-order -- drains those younger operations
+// too.  Touching the value before the loop moves the wait out of it.
+__device__ inline void settle(double v) { asm volatile("" ::"v"(v)); }
+__device__ inline void settle(float v) { asm volatile("" ::"v"(v)); }
+
 // sqrt(max(c, 0)) for the CSM epilogue.  float64: v_rsq_f64 seed, one Goldschmidt step and two
 // Newton corrections (the sequence the compiler's own sqrt uses, correctly rounded), but without
 // the per-element exponent rescaling and class tests: zero flows through the iteration exactly

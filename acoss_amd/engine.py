@@ -170,7 +170,7 @@ def csm_packed(corpus, batch, xp, out=None):
     return out
 
 
-def crp(corpus, batch, xp, sqrt_out=False, out=None):
+def crp(corpus, batch, xp, sqrt_out=False, out=None, force_valu=False, force_tile=False):
     """get_csm + sliding_csm fused (CRPUtils.py:67 + :24): windowed sums of squared distances
     (sqrt_out=False) or their square roots = sliding_csm's output (sqrt_out=True); float64."""
     lib = _lib.load()
@@ -178,7 +178,8 @@ def crp(corpus, batch, xp, sqrt_out=False, out=None):
         out = torch.empty(max(batch.total_crp, 1), dtype=torch.float64, device=corpus.device)
     fn = lib.acoss_crp_batch_f64 if corpus.dtype == np.float64 else lib.acoss_crp_batch_f32
     check(fn(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K,
-             batch.win, batch.max_nx, batch.max_ny, int(bool(sqrt_out)), _ptr(out), _stream()), "crp_batch")
+             batch.win, batch.max_nx, batch.max_ny, int(bool(sqrt_out)) | (2 if force_valu else 0) | (4 if force_tile else 0), _ptr(out),
+             _stream()), "crp_batch")
     return out
 
 

@@ -158,8 +158,10 @@ int acoss_csm_batch_f32(const float *feats, const float *norms, int d,
  *   acoss_crp_batch_*         = get_csm followed by sliding_csm without the CSM ever reaching HBM:
  *                               out[crp_off + i*crp_pitch + j] = sum_{k<win} C[i+k][j+k] when sqrt_out == 0
  *                               (C = clamped squared distance; the square of what sliding_csm returns --
- *                               the kNN selection only needs the order), or its sqrt when sqrt_out != 0.
- *                               d in {12, 13}, win <= 16. */
+ *                               the kNN selection only needs the order), or its sqrt when bit 0 of sqrt_out
+ *                               is set.  d in {12, 13}, win <= 16.  The float64 kernel runs the K = d
+ *                               contraction on the matrix cores (v_mfma_f64_16x16x4_f64); bit 1 of sqrt_out
+ *                               selects the all-VALU form instead (A/B tests). */
 int64_t acoss_xpack_elems(int K, int max_nx);
 int acoss_pack_x_f64(const double *feats, const double *norms, int d, const acoss_pair_desc *descs, int K,
                      int max_nx, double *xp, void *stream);

@@ -40,6 +40,11 @@ def test_fused_kernels_against_reference_stages(eng, golden, c):
     Tbuf = eng.crp(corpus, batch, xp, sqrt_out=False)
     T = _mat(Tbuf, batch, 0, "crp")
     assert np.max(np.abs(T - g[p + "S"] ** 2)) <= 1e-9
+    # the three forms of the float64 kernel (persistent strips on the matrix cores = default, tiled on
+    # the matrix cores, tiled all-VALU) agree bit for bit: a float64 MFMA is a k-ordered FMA chain
+    Tv = _mat(eng.crp(corpus, batch, xp, sqrt_out=False, force_valu=True), batch, 0, "crp")
+    Tt = _mat(eng.crp(corpus, batch, xp, sqrt_out=False, force_tile=True), batch, 0, "crp")
+    assert np.array_equal(T, Tv) and np.array_equal(T, Tt)
     # selection on the squared sums gives the reference's masks
     assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=False), batch, 0, "crp"), g[p + "B1"])
     assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=True), batch, 0, "crp"), g[p + "B"])

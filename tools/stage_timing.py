@@ -51,6 +51,8 @@ Tb = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
 _, t = timed("crp (squared)", lambda: engine.crp(corpus, batch, xp, False, out=Tb)); tf += t
 print("   crp: %.1f GB/s of output (7.87 MB/pair)" % (K * 7.872e6 / (t * 1e-3) / 1e9))
 _, t2 = timed("crp (sqrt)", lambda: engine.crp(corpus, batch, xp, True, out=Tb))
+_, t2 = timed("crp (squared, VALU tile)", lambda: engine.crp(corpus, batch, xp, False, out=Tb, force_valu=True))
+_, t2 = timed("crp (squared, MFMA tile)", lambda: engine.crp(corpus, batch, xp, False, out=Tb, force_tile=True))
 engine.crp(corpus, batch, xp, False, out=Tb)
 _, t = timed("binarize(T)", lambda: engine.binarize(Tb, batch, 0.095, True, out=Bout, work=work)); tf += t
 _, t = timed("qmax", lambda: engine.align("qmax", Bout, mats)); tf += t
