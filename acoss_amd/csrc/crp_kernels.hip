@@ -5,6 +5,7 @@
 #include "common.h"
 #include "wave_ops.h"
 #include "kernel_utils.h"
+#include "thresh_work.h"
 
 #include <math.h>
 
@@ -267,13 +268,6 @@ __global__ __launch_bounds__(256) void sliding_kernel(const T *__restrict__ csm,
 // with one wave per column.
 // thr[] holds the order-preserving key of the threshold value, cut[] the tie cut index.
 // ---------------------------------------------------------------------------------------------
-struct ThreshWork {
-    uint64_t *row_thr;   // [K][max_m]
-    uint64_t *col_thr;   // [K][max_n]
-    int *row_cut;        // [K][max_m]
-    int *col_cut;        // [K][max_n]
-    int max_m, max_n;
-};
 
 __device__ inline void store_uniform_select(int k, int n, uint64_t *thr, int *cut, const SelectResult &r)
 {
@@ -614,12 +608,7 @@ int acoss_dev_select_probe(int mode, const double *S, const acoss_pair_desc *des
                            int max_ny, double kappa, void *work, void *stream)
 {
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    ThreshWork w;
-    w.max_m = max_m; w.max_n = max_n;
-    w.row_thr = (uint64_t *)work;
-    w.col_thr = w.row_thr + (size_t)K * max_m;
-    w.row_cut = (int *)(w.col_thr + (size_t)K * max_n);
-    w.col_cut = w.row_cut + (size_t)K * max_m;
+    ThreshWork w = thresh_work_layout(work, K, max_m, max_n);
     const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
     const unsigned blocks = (unsigned)((int64_t)K * rb);
     hipStream_t st = (hipStream_t)stream;
@@ -661,41 +650,33 @@ size_t acoss_binarize_work_bytes(int K, int max_nx, int max_ny, int win)
     return (size_t)(K > 0 ? K : 0) * (m + n) * (sizeof(uint64_t) + sizeof(int)) + 64;
 }
 
-int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
-                         int max_ny, double kappa, int mutual, uint8_t *B, void *work,
-                         size_t work_bytes, void *stream)
+static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                          double kappa, int mutual, void *work, size_t work_bytes, hipStream_t st, ThreshWork &w)
 {
-    if (!S || !descs || !B || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
-        set_error("binarize_batch: bad argument");
+    if (!S || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
+        set_error("thresholds: bad argument");
         return ACOSS_EINVAL;
     }
-    if (K == 0) return ACOSS_OK;
     if (work_bytes < acoss_binarize_work_bytes(K, max_nx, max_ny, win)) {
-        set_error("binarize_batch: workspace too small");
+        set_error("thresholds: workspace too small");
         return ACOSS_EINVAL;
     }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     if (max_m > 2048 || max_n > 2048) {
-        set_error("binarize_batch: matrices larger than 2048 x 2048 are not supported yet");
+        set_error("thresholds: matrices larger than 2048 x 2048 are not supported yet");
         return ACOSS_ENOTSUP;
     }
-    hipStream_t st = (hipStream_t)stream;
-    ThreshWork w;
-    w.max_m = max_m;
-    w.max_n = max_n;
-    w.row_thr = (uint64_t *)work;
-    w.col_thr = w.row_thr + (size_t)K * max_m;
-    w.row_cut = (int *)(w.col_thr + (size_t)K * max_n);
-    w.col_cut = w.row_cut + (size_t)K * max_m;
+    w = thresh_work_layout(work, K, max_m, max_n);
+    if (K == 0) return ACOSS_OK;
     double kv;
     int mode;
     kappa_mode(kappa, kv, mode);
     {
         const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
         if (max_n <= 1024)
-            hipLaunchKernelGGL(select_rows_kernel<16>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
+            hipLaunchKernelGGL((select_rows_kernel<16>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
         else
-            hipLaunchKernelGGL(select_rows_kernel<32>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
+            hipLaunchKernelGGL((select_rows_kernel<32>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
         int rc = launch_check("select_rows_kernel");
         if (rc) return rc;
     }
@@ -713,11 +694,28 @@ int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, i
         int rc = launch_check("select_cols_kernel");
         if (rc) return rc;
     }
-    {
-        const int cbk = ceil_div(max_n, 1024), rbk = ceil_div(max_m, MASK_ROWS);
-        hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((int64_t)K * cbk * rbk)), dim3(256), 0, st, S, descs, win, mutual, w, cbk, rbk, B);
-        return launch_check("mask_kernel");
-    }
+    return ACOSS_OK;
+}
+
+int acoss_thresholds_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                           double kappa, int mutual, void *work, size_t work_bytes, void *stream)
+{
+    ThreshWork w;
+    return run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, (hipStream_t)stream, w);
+}
+
+int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                         int max_ny, double kappa, int mutual, uint8_t *B, void *work,
+                         size_t work_bytes, void *stream)
+{
+    if (!B) { set_error("binarize_batch: bad argument"); return ACOSS_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ThreshWork w;
+    int rc = run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, st, w);
+    if (rc || K == 0) return rc;
+    const int cbk = ceil_div(w.max_n, 1024), rbk = ceil_div(w.max_m, MASK_ROWS);
+    hipLaunchKernelGGL(mask_kernel, dim3((unsigned)((int64_t)K * cbk * rbk)), dim3(256), 0, st, S, descs, win, mutual, w, cbk, rbk, B);
+    return launch_check("mask_kernel");
 }
 
 }  // extern "C"

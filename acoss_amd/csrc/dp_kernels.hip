@@ -11,6 +11,9 @@
 // when the caller passes a buffer (parity / drop-in use).
 #include "common.h"
 #include "wave_ops.h"
+#include "thresh_work.h"
+
+#include <math.h>
 
 namespace acoss {
 
@@ -326,6 +329,186 @@ __global__ __launch_bounds__(256) void dp_block_kernel(const uint8_t *__restrict
     if (threadIdx.x == 0) scores[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
 }
 
+// ---------------------------------------------------------------------------------------------
+// Mask + alignment fused (the product path): the wave that sweeps a pair's rows reads the rows of the
+// windowed squared sums (acoss_crp_batch output, non-negative) and the kNN thresholds, forms the mutual
+// mask bits of its 16 columns in registers and feeds them to the recurrence.  The uint8 mask is never
+// written or read; per pair the kernel streams 8 bytes per cell once and emits one float.
+// Constant gap penalty only (gamma_onset == gamma_extension, the reference's 0.5 / 0.5), columns <= 1024.
+// ---------------------------------------------------------------------------------------------
+__device__ inline double thr_value(uint64_t key)
+{
+    // keys of non-negative values have the sign bit set; 0 = "select nothing", ~0 = "select everything"
+    if (key == ~0ull) return INFINITY;
+    if ((key >> 63) == 0) return -1.0;
+    return __longlong_as_double((long long)(key & 0x7fffffffffffffffull));
+}
+
+template <int KIND>
+__global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restrict__ T,
+                                                          const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                          ThreshWork w, int mutual, float gamma, int boundary,
+                                                          float *__restrict__ scores)
+{
+    constexpr int CPL = 16;
+    constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
+    constexpr int R0 = (KIND == KIND_DMAX) ? 1 : 2;     // first row whose mask is needed
+    constexpr int PF = 2;                               // rows of T in flight (32 VGPRs each)
+    // The 16 column thresholds of a lane are re-read every row: they live in LDS ([column][lane], so a
+    // wave's read of one column slot is 512 contiguous bytes), not in 48 VGPRs.  Every lane reads only
+    // what it wrote itself, so no barrier is involved.
+    __shared__ double ct_lds[4][CPL][64];
+    __shared__ int cc_lds[4][CPL][64];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (M < FIRST + 1 || N < FIRST + 1) {
+        if (lane == 0) scores[p] = 0.0f;
+        return;
+    }
+    const int j0 = lane * CPL;
+    const double *base = T + ds.crp_off;
+    const int last = ((N + 1) & ~1) - 2;     // last aligned pair of a row (the pitch is even and >= N)
+    double (*ctw)[64] = ct_lds[wave];
+    int (*ccw)[64] = cc_lds[wave];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) {
+        const int j = j0 + c;
+        double tv = -1.0;      // columns past the matrix: never selected
+        int cv = -1;
+        if (j < N) {
+            tv = mutual ? thr_value(w.col_thr[(int64_t)p * w.max_n + j]) : INFINITY;
+            cv = mutual ? w.col_cut[(int64_t)p * w.max_n + j] : 0x7fffffff;
+        }
+        ctw[c][lane] = tv;
+        ccw[c][lane] = cv;
+    }
+    auto load_row = [&](const int i, double (&dst)[CPL]) {
+        const double *row = base + (int64_t)i * ds.crp_pitch;
+#pragma unroll
+        for (int q = 0; q < CPL / 2; q++) {
+            const double2 v = *reinterpret_cast<const double2 *>(row + min(j0 + 2 * q, last));
+            dst[2 * q] = v.x;
+            dst[2 * q + 1] = v.y;
+        }
+    };
+    double ring[PF][CPL];
+#pragma unroll
+    for (int u = 0; u < PF; u++) load_row(min(R0 + u, M - 1), ring[u]);
+
+    float d1[CPL], d2[CPL], d3[CPL];
+    unsigned m1 = 0, m2 = 0;               // mask bits of rows i-1, i-2 (dmax)
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { d1[c] = d2[c] = d3[c] = 0.f; }
+    float best = 0.0f;
+    const bool l0 = lane == 0;
+    double rt_lane = -1.0;     // row thresholds of rows (i & ~63) + lane
+    int rc_lane = -1;
+    int rt_block = -1;
+
+    auto do_row = [&](const int i, double (&t)[CPL]) {
+        if ((i >> 6) != rt_block) {          // wave-uniform: fetch the next 64 row thresholds
+            rt_block = i >> 6;
+            const int r = min((rt_block << 6) + lane, M - 1);
+            rt_lane = thr_value(w.row_thr[(int64_t)p * w.max_m + r]);
+            rc_lane = w.row_cut[(int64_t)p * w.max_m + r];
+        }
+        const int sel = i & 63;
+        const double rt = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(rt_lane), sel),
+                                           __builtin_amdgcn_readlane(__double2loint(rt_lane), sel));
+        const int rc = __builtin_amdgcn_readlane(rc_lane, sel);
+        unsigned m0 = 0;                     // this row's mask bits, bit c = column j0 + c
+        bool col_tie = false;
+#pragma unroll
+        for (int c = 0; c < CPL; c++) {
+            const int j = j0 + c;
+            const double ctv = ctw[c][lane];
+            // bitwise, not short-circuit, logic: no divergent branches per element
+            const bool row_on = (t[c] < rt) | ((t[c] == rt) & (j <= rc));
+            const bool col_on = t[c] < ctv;
+            col_tie |= (t[c] == ctv);
+            m0 |= ((row_on & col_on) ? 1u : 0u) << c;
+        }
+        if (__any(col_tie)) {                // a value equal to its column threshold: apply the tie cut
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const int j = j0 + c;
+                const bool row_on = (t[c] < rt) | ((t[c] == rt) & (j <= rc));
+                const bool eq = (t[c] == ctw[c][lane]) & (i <= ccw[c][lane]);
+                m0 |= ((row_on & eq) ? 1u : 0u) << c;
+            }
+        }
+        // the slot is consumed: refill it with the row PF steps ahead before the recurrence
+        if (i + PF < M) load_row(i + PF, t);
+        if (i >= FIRST) {
+            const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
+            const float h2a = lane_shr1(d2[CPL - 1], 0.f);
+            float h1c = 0.f, h3a = 0.f;
+            unsigned h0 = 0;                 // mask bits of lane l-1 (columns j0-16 .. j0-1)
+            if (KIND == KIND_DMAX) {
+                h1c = lane_shr1(d1[CPL - 3], 0.f);
+                h3a = lane_shr1(d3[CPL - 1], 0.f);
+                h0 = (unsigned)lane_shr1((int)m0, 0);
+            }
+            const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);     // bit c+2 = S[i][j0 + c], bits 1,0 = j0-1, j0-2
+            float nd[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const float p_diag = c >= 1 ? d1[c - 1] : h1a;
+                const float p_up2 = c >= 1 ? d2[c - 1] : h2a;
+                const float p_left2 = c >= 2 ? d1[c - 2] : (c == 1 ? h1a : h1b);
+                float m = max3f(p_diag, p_up2, p_left2);
+                if (KIND == KIND_DMAX) {
+                    const float p_up3 = c >= 1 ? d3[c - 1] : h3a;
+                    const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));
+                    const float s_u1 = (float)((m1 >> c) & 1u);            // S[i-1][j]
+                    const float s_u2 = (float)((m2 >> c) & 1u);            // S[i-2][j]
+                    const float s_l1 = (float)((ext >> (c + 1)) & 1u);     // S[i][j-1]
+                    const float s_l2 = (float)((ext >> c) & 1u);           // S[i][j-2]
+                    const float c2 = p_up2 + s_u1;
+                    const float c3 = p_left2 + s_l1;
+                    const float c4 = (p_up3 + s_u2) + s_u1;
+                    const float c5 = (p_left3 + s_l2) + s_l1;
+                    m = fmaxf(fmaxf(max3f(p_diag, c2, c3), c4), c5);
+                }
+                const bool on = (m0 >> c) & 1u;
+                float v = fmaxf(m + (on ? 1.0f : -gamma), 0.0f);
+                if (c < FIRST) {
+                    // columns the recurrence never writes (lane 0 only): zero, or what qmax leaves in
+                    // column 2 of a shared D (Serra09.py:173-175)
+                    const float bval = (KIND == KIND_DMAX && c == 2 && boundary) ? (float)((m0 >> 2) & 1u) : 0.0f;
+                    best = fmaxf(best, l0 ? 0.0f : v);
+                    v = l0 ? bval : v;
+                } else {
+                    best = fmaxf(best, v);
+                }
+                nd[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) { d3[c] = d2[c]; d2[c] = d1[c]; d1[c] = nd[c]; }
+        } else if (KIND == KIND_DMAX && i == 2) {
+            // row 2 of D as qmax leaves it on a shared buffer: (S[2][j] == 1) for j >= 2, else zero
+#pragma unroll
+            for (int c = 0; c < CPL; c++) d1[c] = (boundary && j0 + c >= 2) ? (float)((m0 >> c) & 1u) : 0.0f;
+        }
+        m2 = m1;
+        m1 = m0;
+    };
+    for (int ib = R0; ib < M; ib += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = ib + u;
+            if (i < M) do_row(i, ring[u]);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if (lane == 0) scores[p] = best;
+}
+
 template <int KIND>
 static int launch_dp(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
                      int boundary, const acoss_align_params *params, float *scores, hipStream_t st)
@@ -373,6 +556,33 @@ int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max
                     const acoss_align_params *params, float *scores, void *stream)
 {
     return launch_dp<KIND_SWC>(S, mats, K, max_cols, D, 0, params, scores, (hipStream_t)stream);
+}
+
+int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                            int max_ny, int mutual, const void *work, size_t work_bytes, int boundary,
+                            const acoss_align_params *params, float *scores, void *stream)
+{
+    if (!T || !descs || !work || !scores || K < 0 || win < 1 || max_nx < win || max_ny < win || (kind != 0 && kind != 1)) {
+        set_error("align_fused_batch: bad argument (kind 0 = qmax, 1 = dmax)");
+        return ACOSS_EINVAL;
+    }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    acoss_align_params ap;
+    if (params) ap = *params; else acoss_default_align_params(&ap);
+    if (max_n > 1024 || ap.gamma_onset != ap.gamma_extension) {
+        set_error("align_fused_batch: needs <= 1024 columns and gamma_onset == gamma_extension "
+                  "(use acoss_binarize_batch + acoss_qmax_batch / acoss_dmax_batch otherwise)");
+        return ACOSS_ENOTSUP;
+    }
+    if (work_bytes < (size_t)K * (size_t)(max_m + max_n) * 12) { set_error("align_fused_batch: workspace too small"); return ACOSS_EINVAL; }
+    if (K == 0) return ACOSS_OK;
+    ThreshWork w = thresh_work_layout(const_cast<void *>(work), K, max_m, max_n);
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0)
+        hipLaunchKernelGGL(dp_fused_kernel<KIND_QMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, T, descs, K, win, w, mutual, ap.gamma_onset, 0, scores);
+    else
+        hipLaunchKernelGGL(dp_fused_kernel<KIND_DMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, T, descs, K, win, w, mutual, ap.gamma_onset, boundary, scores);
+    return launch_check("dp_fused_kernel");
 }
 
 }  // extern "C"

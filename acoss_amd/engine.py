@@ -212,6 +212,34 @@ def binarize(S_buf, batch, kappa, mutual=True, out=None, work=None):
     return out
 
 
+def thresholds(S_buf, batch, kappa, mutual=True, work=None):
+    """Row (and column) kNN thresholds of every pair's matrix; returns the workspace tensor."""
+    lib = _lib.load()
+    need = int(lib.acoss_binarize_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=S_buf.device)
+    check(lib.acoss_thresholds_batch(_ptr(S_buf), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
+                                     batch.max_ny, float(kappa), int(bool(mutual)), _ptr(work), work.numel(),
+                                     _stream()), "thresholds_batch")
+    return work
+
+
+def align_fused(kind, T_buf, batch, work, mutual=True, boundary=0, params=None, scores=None):
+    """qmax / dmax straight from the windowed sums and their thresholds (no mask in memory)."""
+    lib = _lib.load()
+    if scores is None:
+        scores = torch.empty(max(batch.K, 1), dtype=torch.float32, device=T_buf.device)
+    pp = ctypes.byref(params) if params is not None else None
+    check(lib.acoss_align_fused_batch({"qmax": 0, "dmax": 1}[kind], _ptr(T_buf), _ptr(batch.descs_dev), batch.K,
+                                      batch.win, batch.max_nx, batch.max_ny, int(bool(mutual)), _ptr(work),
+                                      work.numel(), int(boundary), pp, _ptr(scores), _stream()), "align_fused_batch")
+    return scores[:batch.K]
+
+
+def fused_align_supported(batch):
+    return batch.max_ny - batch.win + 1 <= 1024
+
+
 def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None, mats_dev=None, scores=None):
     """SequenceAlignment.c recurrences over a batch of matrices.  kind in {'qmax','dmax','swc'}.
     mats: numpy MAT_DESC array (mats_dev: the same bytes already on the device, to keep the
@@ -269,9 +297,16 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
             T = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
         crp(corpus, batch, xp, sqrt_out=False, out=T)
+        denom = (batch.M + batch.N).astype(np.float64)
+        if fused_align_supported(batch):
+            work = thresholds(T, batch, kappa, mutual=True, work=work)
+            if "qmax" in want:
+                out["qmax"][lo:lo + len(sel)] = align_fused("qmax", T, batch, work).cpu().numpy().astype(np.float64) / denom
+            if "dmax" in want:
+                out["dmax"][lo:lo + len(sel)] = align_fused("dmax", T, batch, work, boundary=1).cpu().numpy().astype(np.float64) / denom
+            continue
         binarize(T, batch, kappa, mutual=True, out=B, work=work)
         mats, _ = batch.mats()
-        denom = (batch.M + batch.N).astype(np.float64)
         if "qmax" in want:
             out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats).cpu().numpy().astype(np.float64) / denom
         if "dmax" in want:

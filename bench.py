@@ -51,14 +51,16 @@ def parse():
     return ap.parse_args()
 
 
-STAGES = {"fast": ["oti", "pack_x", "crp", "binarize", "qmax"],
+STAGES = {"fast": ["oti", "pack_x", "crp", "thresholds", "qmax_fused"],
           "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
 
 
 class Runner(object):
-    """One step = OTI -> [fast: pack_x -> crp (fused CSM + sliding window) | staged: CSM -> sliding]
-    -> mutual kNN binarisation -> qmax.  All buffers are preallocated and every launch goes to
-    torch's current stream; HIP events between the stages give per-kernel times of the timed steps."""
+    """One step, fast path: OTI -> pack_x -> crp (fused CSM + sliding window, squared) -> row/column kNN
+    thresholds -> qmax fused with the mask (no mask in memory).  Staged path: OTI -> CSM -> sliding ->
+    binarise (thresholds + mask) -> qmax, one kernel per reference function.  All buffers are
+    preallocated and every launch goes to torch's current stream; HIP events between the stages give
+    per-stage times of the timed steps."""
 
     def __init__(self, corpus, batches, m, kappa, path):
         import torch
@@ -107,9 +109,14 @@ class Runner(object):
             mark(2)
             e.sliding(self.C, b, out=self.S)
         mark(3)
-        e.binarize(self.S, b, self.kappa, True, out=self.B, work=self.work)
-        mark(4)
-        e.align("qmax", self.B, mats, mats_dev=mats_dev, max_cols=max_cols, scores=scores_out)
+        if self.path == "fast":
+            e.thresholds(self.S, b, self.kappa, True, work=self.work)
+            mark(4)
+            e.align_fused("qmax", self.S, b, self.work, scores=scores_out)
+        else:
+            e.binarize(self.S, b, self.kappa, True, out=self.B, work=self.work)
+            mark(4)
+            e.align("qmax", self.B, mats, mats_dev=mats_dev, max_cols=max_cols, scores=scores_out)
         mark(5)
 
 

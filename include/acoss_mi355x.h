@@ -198,6 +198,19 @@ int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, i
                          int max_nx, int max_ny, double kappa, int mutual, uint8_t *B,
                          void *work, size_t work_bytes, void *stream);
 
+/* The two halves of acoss_binarize_batch separately.  acoss_thresholds_batch computes only the per-row
+ * (and, when mutual, per-column) kNN thresholds of S into `work` (acoss_binarize_work_bytes()).
+ * acoss_align_fused_batch then runs qmax (kind 0) or dmax (kind 1) directly from S and those thresholds,
+ * forming the mask bits in registers inside the alignment sweep: the uint8 mask never exists in memory.
+ * Requirements: S non-negative (the output of acoss_crp_batch_*), every pitch and offset of the descs
+ * even, at most 1024 columns, gamma_onset == gamma_extension; otherwise ACOSS_ENOTSUP and the caller
+ * uses acoss_binarize_batch + acoss_qmax_batch / acoss_dmax_batch.  `boundary` as for acoss_dmax_batch. */
+int acoss_thresholds_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                           int max_ny, double kappa, int mutual, void *work, size_t work_bytes, void *stream);
+int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *descs, int K, int win,
+                            int max_nx, int max_ny, int mutual, const void *work, size_t work_bytes,
+                            int boundary, const acoss_align_params *params, float *scores, void *stream);
+
 /* SequenceAlignment.c:113 / :147 / :73 over a batch of matrices.  S and D are the bases the
  * descs' offsets refer to; D may be NULL (scores only: the reference's callers never read D,
  * Serra09.py:174-175).  When D is given it is read AND written exactly like the reference's

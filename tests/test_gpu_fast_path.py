@@ -93,3 +93,22 @@ def test_fast_chain_ragged_and_other_windows(eng, orc):
         res = eng.serra09_scores(corpus, sel, m=m, kappa=kappa)
         q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, sel, m=m, kappa=kappa, nthreads=4)
         assert np.array_equal(res["qmax"], q) and np.array_equal(res["dmax"], d), m
+
+
+def test_fused_alignment_equals_mask_then_alignment(eng, golden):
+    """qmax / dmax computed straight from the windowed sums and thresholds == the same recurrences on
+    the materialised mask, in every boundary mode, one-sided and mutual."""
+    g = golden("pairs_1000")
+    corpus = eng.DeviceCorpus(g["feats"], g["frame_off"], gchroma=g["gchroma"])
+    batch = eng.PairBatch(corpus.frame_off, g["pairs"], 9, corpus.device)
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    mats, _ = batch.mats()
+    for mutual in (True, False):
+        B = eng.binarize(T, batch, 0.095, mutual=mutual)
+        work = eng.thresholds(T, batch, 0.095, mutual=mutual)
+        assert np.array_equal(eng.align_fused("qmax", T, batch, work, mutual=mutual).cpu().numpy(),
+                              eng.align("qmax", B, mats).cpu().numpy())
+        for boundary in (0, 1):
+            assert np.array_equal(eng.align_fused("dmax", T, batch, work, mutual=mutual, boundary=boundary).cpu().numpy(),
+                                  eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())

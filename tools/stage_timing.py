@@ -54,9 +54,11 @@ _, t2 = timed("crp (sqrt)", lambda: engine.crp(corpus, batch, xp, True, out=Tb))
 _, t2 = timed("crp (squared, VALU tile)", lambda: engine.crp(corpus, batch, xp, False, out=Tb, force_valu=True))
 _, t2 = timed("crp (squared, MFMA tile)", lambda: engine.crp(corpus, batch, xp, False, out=Tb, force_tile=True))
 engine.crp(corpus, batch, xp, False, out=Tb)
-_, t = timed("binarize(T)", lambda: engine.binarize(Tb, batch, 0.095, True, out=Bout, work=work)); tf += t
-_, t = timed("qmax", lambda: engine.align("qmax", Bout, mats)); tf += t
-print("fast chain (oti+pack+crp+binarize+qmax): %.3f ms for %d pairs -> %.0f pair-scores/s" % (tf + 0.03, K, K / ((tf + 0.03) * 1e-3)))
+_, t = timed("binarize(T)", lambda: engine.binarize(Tb, batch, 0.095, True, out=Bout, work=work))
+_, t = timed("thresholds(T)", lambda: engine.thresholds(Tb, batch, 0.095, True, work=work)); tf += t
+_, t = timed("qmax fused", lambda: engine.align_fused("qmax", Tb, batch, work)); tf += t
+_, t2 = timed("dmax fused", lambda: engine.align_fused("dmax", Tb, batch, work, boundary=1))
+print("fast chain (oti+pack+crp+thresholds+qmax_fused): %.3f ms for %d pairs -> %.0f pair-scores/s" % (tf + 0.03, K, K / ((tf + 0.03) * 1e-3)))
 # f32 csm
 c32 = engine.DeviceCorpus(corpus_h.feats.astype(np.float32), corpus_h.frame_off, gchroma=corpus_h.gchroma)
 _, t = timed("csm_f32", lambda: engine.csm(c32, batch))
