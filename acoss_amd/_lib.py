@@ -59,6 +59,7 @@ SIGNATURES = {
     "acoss_pack_x_f32": (_i, [_vp, _vp, _i, _vp, _i, _i, _vp, _vp]),
     "acoss_csm_packed_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_csm_packed_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "acoss_csm_strip_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_crp_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acoss_crp_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acoss_sliding_batch_f64": (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp]),

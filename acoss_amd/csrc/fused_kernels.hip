@@ -374,7 +374,9 @@ constexpr int STRIP_ROWS = 32;
 
 // MODE (development probes, product = 0): 1 = no result stores, 2 = no window sums (store a C value),
 // 3 = no MFMA phase (stale LDS contents summed)
-template <int D, int WIN, bool SQRT_OUT, int MODE = 0>
+// CSM_LAYOUT: write at the pair's csm_off / csm_pitch instead of crp_off / crp_pitch (WIN = 1 with
+// SQRT_OUT is then exactly get_csm, CRPUtils.py:67-84).
+template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false>
 __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
                                                         const double *__restrict__ feats, const double *__restrict__ norms,
                                                         const acoss_pair_desc *__restrict__ descs, int strips,
@@ -435,9 +437,11 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     // halo copy: thread h < HALO*128 moves element h of rows [32, 32+HALO) to rows [0, HALO)
     const bool copier = threadIdx.x < HALO * (CRP_CT / 2);
     const int hrow = (2 * threadIdx.x) / CRP_CT, hcol = (2 * threadIdx.x) % CRP_CT;
-    double *halo_src = cbuf + (STRIP_ROWS + (copier ? hrow : 0)) * CRP_LD + hcol;
+    double *halo_src = cbuf + ((copier ? STRIP_ROWS + hrow : 0)) * CRP_LD + hcol;
     double *halo_dst = cbuf + (copier ? hrow : 0) * CRP_LD + hcol;
-    double *orow = out + ds.crp_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * ds.crp_pitch;
+    const int64_t o_off = CSM_LAYOUT ? ds.csm_off : ds.crp_off;
+    const int o_pitch = CSM_LAYOUT ? ds.csm_pitch : ds.crp_pitch;
+    double *orow = out + o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;
 
     // x frames are fetched two steps ahead (registers), so their HBM latency spans a whole step
     double2 xn1 = make_double2(0.0, 0.0), xn2 = make_double2(0.0, 0.0);
@@ -500,7 +504,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     sa = csm_sqrt(sa);
                     sb = csm_sqrt(sb);
                 }
-                double *o = orow + (int64_t)(t * STRIP_ROWS + q) * ds.crp_pitch;
+                double *o = orow + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
                 if (MODE == 1) {
                     if (sa == -1.25) o[ca] = sb;
                 } else if (CHECKED) {
@@ -526,7 +530,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         lds_barrier();
         if (copier) *reinterpret_cast<double2 *>(halo_dst) = hv;
     };
-    const bool full_strip = j0 + TN <= N;                     // block-uniform
+    const bool full_strip = (j0 + TN <= N) && ((o_pitch & 1) == 0) && ((o_off & 1) == 0);   // block-uniform
     step(0, std::true_type{});
     if (full_strip) {
         for (int t = 1; t < n_steps - 1; t++) step(t, std::false_type{});
@@ -695,6 +699,24 @@ int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float 
                                const acoss_pair_desc *descs, int K, int max_nx, int max_ny, float *csm, void *stream)
 {
     return launch_csm_packed<float>(xp, feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
+}
+
+// get_csm through the persistent strip kernel (window 1, sqrt): the fast float64 CSM
+int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                              const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm, void *stream)
+{
+    if (!xp || !feats || !norms || !descs || !csm || K < 0 || max_nx < 1 || max_ny < 1) {
+        set_error("csm_strip_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if (d != 12 && d != 13) { set_error("csm_strip_batch: d must be 12 or 13"); return ACOSS_ENOTSUP; }
+    if (K == 0) return ACOSS_OK;
+    const int strips = ceil_div(max_ny, CRP_CT);
+    const unsigned blocks = (unsigned)((int64_t)K * strips);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 12) hipLaunchKernelGGL((crp_strip_kernel<12, 1, true, 0, true>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, csm);
+    else hipLaunchKernelGGL((crp_strip_kernel<13, 1, true, 0, true>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, csm);
+    return launch_check("crp_strip_kernel (csm)");
 }
 
 int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,

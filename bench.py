@@ -188,7 +188,7 @@ def main():
     # dominant HBM-bound kernel of the path: the cross-similarity kernel (fused with the sliding
     # window in the fast path, materialising the CSM in the staged path)
     if args.path == "fast":
-        kname, kms, kbytes = "crp_kernel<double,12,9> (CRPUtils.py:67 + :24 fused)", stage_ms["crp"], runner.crp_bytes
+        kname, kms, kbytes = "crp_strip_kernel<12,9> (CRPUtils.py:67 + :24 fused, f64 MFMA)", stage_ms["crp"], runner.crp_bytes
     else:
         kname, kms, kbytes = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
     kbytes = float(np.mean(kbytes[args.warmup:]))
@@ -212,25 +212,33 @@ def main():
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
     if rank == 0 and args.path == "fast":
-        # the materialising CSM kernel (get_csm as an API, the kernel the north star names) on the
-        # same batch, outside the timed region: reported beside the path's own dominant kernel
-        C = torch.empty(batches[-1].total_csm, dtype=corpus.feats.dtype, device=dev)
-        ms = []
-        for _ in range(4):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            engine.csm(corpus, batches[-1], out=C)
-            e1.record()
-            torch.cuda.synchronize()
-            ms.append(e0.elapsed_time(e1))
-        cms = float(np.median(ms[1:]))
+        # get_csm as an API (the kernel the north star names) on the same batch, outside the timed
+        # region, reported beside the path's own dominant kernel: the plain VALU kernel and the
+        # persistent matrix-core strip kernel (bit-identical outputs)
+        b = batches[-1]
+        C = torch.empty(b.total_csm, dtype=corpus.feats.dtype, device=dev)
         cb = runner.csm_bytes[-1]
-        out["roofline_csm_materialising"] = {"kernel": "csm_kernel<double,12> (CRPUtils.py:67), not on the fast path",
-                                             "bound": "hbm", "achieved": round(cb / cms / 1e6, 1), "peak": HBM_PEAK_GBS,
-                                             "unit": "GB/s", "frac": round(cb / cms / 1e6 / HBM_PEAK_GBS, 4),
-                                             "bytes_per_launch": cb, "avg_launch_ms": round(cms, 4)}
-        del C
 
+        def time_kernel(fn):
+            ms = []
+            for _ in range(5):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                torch.cuda.synchronize()
+                ms.append(e0.elapsed_time(e1))
+            return float(np.median(ms[1:]))
+        xp = engine.pack_x(corpus, b, out=runner.xp)
+        for key, kname2, fn in (("roofline_csm_materialising", "crp_strip_kernel<12,1,sqrt> as get_csm (CRPUtils.py:67), not on the fast path",
+                                 lambda: engine.csm_strip(corpus, b, xp, out=C)),
+                                ("roofline_csm_valu", "csm_kernel<double,12> (CRPUtils.py:67), not on the fast path",
+                                 lambda: engine.csm(corpus, b, out=C))):
+            cms = time_kernel(fn)
+            out[key] = {"kernel": kname2, "bound": "hbm", "achieved": round(cb / cms / 1e6, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(cb / cms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": cb,
+                        "avg_launch_ms": round(cms, 4)}
+        del C
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
         threads = max(1, min(os.cpu_count() or 1, 16))

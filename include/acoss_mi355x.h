@@ -173,6 +173,11 @@ int acoss_csm_packed_batch_f64(const double *xp, const double *feats, const doub
 int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float *norms, int d,
                                const acoss_pair_desc *descs, int K, int max_nx, int max_ny, float *csm,
                                void *stream);
+/* float64 get_csm through the persistent matrix-core strip kernel (same output as acoss_csm_batch_f64
+ * up to the rounding of one FMA-chain order; d in {12, 13}). */
+int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                              const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm,
+                              void *stream);
 int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);

@@ -35,6 +35,8 @@ def test_fused_kernels_against_reference_stages(eng, golden, c):
     C0 = eng.csm(corpus, batch)
     C1 = eng.csm_packed(corpus, batch, xp)
     assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C1, batch, 0, "csm"))     # same arithmetic, bit for bit
+    C2 = eng.csm_strip(corpus, batch, xp)                                           # matrix-core strip kernel
+    assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C2, batch, 0, "csm"))
     S = _mat(eng.crp(corpus, batch, xp, sqrt_out=True), batch, 0, "crp")
     assert np.max(np.abs(S - g[p + "S"])) <= 1e-9
     Tbuf = eng.crp(corpus, batch, xp, sqrt_out=False)

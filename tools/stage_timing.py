@@ -47,6 +47,8 @@ print("chain (oti+csm+sliding+binarize+qmax): %.3f ms for %d pairs -> %.0f pair-
 xp, t = timed("pack_x", lambda: engine.pack_x(corpus, batch)); tf = t
 _, t = timed("csm_packed_f64", lambda: engine.csm_packed(corpus, batch, xp, out=C))
 print("   csm_packed: %.1f GB/s algorithmic" % (K * 8.192e6 / (t * 1e-3) / 1e9))
+_, t = timed("csm_strip_f64", lambda: engine.csm_strip(corpus, batch, xp, out=C))
+print("   csm_strip: %.1f GB/s algorithmic" % (K * 8.192e6 / (t * 1e-3) / 1e9))
 Tb = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
 _, t = timed("crp (squared)", lambda: engine.crp(corpus, batch, xp, False, out=Tb)); tf += t
 print("   crp: %.1f GB/s of output (7.87 MB/pair)" % (K * 7.872e6 / (t * 1e-3) / 1e9))
