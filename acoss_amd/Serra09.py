@@ -130,7 +130,7 @@ class Serra09(CoverAlgorithm):
         songs = np.unique(idxs)
         corpus, where = self._device_corpus(key, [int(s) for s in songs])
         local = np.array([[where[int(a)], where[int(b)]] for a, b in idxs], dtype=np.int32)
-        return engine.serra09_scores_staged(corpus, local, m=win, kappa=self.kappa, do_oti=do_oti)
+        return engine.serra09_scores(corpus, local, m=win, kappa=self.kappa, do_oti=do_oti)
 
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)

@@ -289,7 +289,7 @@ __device__ inline bool trivial_select(int k, int n, SelectResult &r)
 // loads of row r+1 are already in flight (two register buffers, statically alternated), so the
 // HBM latency of a row hides behind the selection of the previous one.  Lane l holds elements
 // 128*q + 2*l + {0,1} of the row (one 16-byte load per q).
-constexpr int SEL_ROWS_PER_WAVE = 12;
+constexpr int SEL_ROWS_PER_WAVE = 8;
 
 // Branch-free: positions past the row end are clamped to the row's last aligned pair (in bounds,
 // the row pitch is even) and masked out when the keys are formed, so all EPL/2 loads of a row issue
@@ -374,23 +374,15 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restri
         }
         return;
     }
-    // three row buffers, statically rotated: rows i+1 and i+2 are in flight while row i is selected
-    double bufC[EPL];
     load_row_pairs<EPL>(base + (int64_t)r0 * ds.crp_pitch, N, lane, vec_ok, bufA);
-    if (r0 + 1 < r1) load_row_pairs<EPL>(base + (int64_t)(r0 + 1) * ds.crp_pitch, N, lane, vec_ok, bufB);
-    for (int i = r0; i < r1; i += 3) {
-        if (i + 2 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 2) * ds.crp_pitch, N, lane, vec_ok, bufC);
+    for (int i = r0; i < r1; i += 2) {
+        if (i + 1 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 1) * ds.crp_pitch, N, lane, vec_ok, bufB);
         SelectResult res = select_from_buf<EPL>(bufA, N, k, lane);
         store_uniform_select(k, N, thr + i, cut + i, res);
         if (i + 1 < r1) {
-            if (i + 3 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 3) * ds.crp_pitch, N, lane, vec_ok, bufA);
+            if (i + 2 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 2) * ds.crp_pitch, N, lane, vec_ok, bufA);
             res = select_from_buf<EPL>(bufB, N, k, lane);
             store_uniform_select(k, N, thr + i + 1, cut + i + 1, res);
-        }
-        if (i + 2 < r1) {
-            if (i + 4 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 4) * ds.crp_pitch, N, lane, vec_ok, bufB);
-            res = select_from_buf<EPL>(bufC, N, k, lane);
-            store_uniform_select(k, N, thr + i + 2, cut + i + 2, res);
         }
     }
 }
