@@ -386,6 +386,11 @@ __global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restri
         ctw[c][lane] = tv;
         ccw[c][lane] = cv;
     }
+    // bit c set iff column j0 + c exists: slots past the row end hold clamped duplicates or, for odd N,
+    // one uninitialised padding element -- never let them into the mask
+    unsigned colmask = 0;
+#pragma unroll
+    for (int c = 0; c < CPL; c++) colmask |= (j0 + c < N ? 1u : 0u) << c;
     auto load_row = [&](const int i, double (&dst)[CPL]) {
         const double *row = base + (int64_t)i * ds.crp_pitch;
 #pragma unroll
@@ -441,6 +446,7 @@ __global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restri
                 m0 |= ((row_on & eq) ? 1u : 0u) << c;
             }
         }
+        m0 &= colmask;
         // the slot is consumed: refill it with the row PF steps ahead before the recurrence
         if (i + PF < M) load_row(i + PF, t);
         if (i >= FIRST) {

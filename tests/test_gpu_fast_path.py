@@ -114,3 +114,24 @@ def test_fused_alignment_equals_mask_then_alignment(eng, golden):
         for boundary in (0, 1):
             assert np.array_equal(eng.align_fused("dmax", T, batch, work, mutual=mutual, boundary=boundary).cpu().numpy(),
                                   eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())
+
+
+def test_results_do_not_depend_on_stale_device_memory(eng, orc):
+    """Buffers come from torch.empty: padding elements (odd widths, pitch rounding) hold whatever the
+    allocator's previous tenant left.  Poison the pool with adversarial bit patterns (negative, huge,
+    NaN, small positive) and check that scores on odd-sized ragged pairs do not move."""
+    import torch
+    from acoss_amd import synth
+    lens = iter([41, 57, 99, 123, 201, 333])
+    ch = synth.make_corpus(3, 2, seed=81, lengths=lambda r: next(lens))
+    pairs = np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32)
+    q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=4)
+    for fill in (-1e300, 1e-300, float("nan"), -3.5, 0.0):
+        junk = [torch.full((1 << 24,), fill, dtype=torch.float64, device="cuda") for _ in range(6)]
+        rnd = torch.randint(-2 ** 62, 2 ** 62, (1 << 24,), dtype=torch.int64, device="cuda")
+        del junk, rnd
+        corpus = eng.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+        for fn in (eng.serra09_scores, eng.serra09_scores_staged):
+            res = fn(corpus, pairs, batch_pairs=13)
+            assert np.array_equal(res["qmax"], q) and np.array_equal(res["dmax"], d), (fill, fn.__name__)
+        del corpus
