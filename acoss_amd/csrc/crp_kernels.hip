@@ -317,18 +317,24 @@ __device__ inline void load_row_pairs(const double *row, int N, int lane, bool v
 }
 
 template <int EPL>
-__device__ inline SelectResult select_from_buf(const double (&buf)[EPL], int N, int k, int lane)
+__device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k, int lane, unsigned &warm)
 {
     SelectResult res;
     if (trivial_select(k, N, res)) return res;
-    uint64_t key[EPL];
-    int idx[EPL];
 #pragma unroll
-    for (int e = 0; e < EPL; e++) {
-        idx[e] = 128 * (e >> 1) + 2 * lane + (e & 1);
-        key[e] = idx[e] < N ? f64_key(buf[e]) : ~0ull;
+    for (int e = 0; e < EPL; e++) buf[e] = buf[e] + 0.0;     // -0.0 -> +0.0
+    if constexpr (EPL == 16) {
+        return wave_select16(buf, RowIdx{lane}, N, k, warm);
+    } else {
+        uint64_t key[EPL];
+        int idx[EPL];
+#pragma unroll
+        for (int e = 0; e < EPL; e++) {
+            idx[e] = 128 * (e >> 1) + 2 * lane + (e & 1);
+            key[e] = idx[e] < N ? key_of(buf[e]) : ~0ull;
+        }
+        return wave_select_kth<EPL>(key, idx, N, k);
     }
-    return wave_select_kth<EPL>(key, idx, N, k);
 }
 
 // MODE (development probes, product = 0): 1 = row loads only, 2 = selection only (synthetic values)
@@ -354,7 +360,7 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restri
     const bool vec_ok = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);
     uint64_t *thr = w.row_thr + (int64_t)p * w.max_m;
     int *cut = w.row_cut + (int64_t)p * w.max_m;
-    double bufA[EPL], bufB[EPL];
+    double bufA[EPL];
     if constexpr (MODE == 1) {
         for (int i = r0; i < r1; i++) {
             load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, bufA);
@@ -369,21 +375,20 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restri
         for (int i = r0; i < r1; i++) {
 #pragma unroll
             for (int e = 0; e < EPL; e++) bufA[e] = (double)((lane * 2654435761u + e * 40503u + i * 97u) & 0xfffff) * 1e-3 + 0.5;
-            SelectResult res = select_from_buf<EPL>(bufA, N, k, lane);
+            unsigned cold = 0;
+            SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, cold);
             store_uniform_select(k, N, thr + i, cut + i, res);
         }
         return;
     }
-    load_row_pairs<EPL>(base + (int64_t)r0 * ds.crp_pitch, N, lane, vec_ok, bufA);
-    for (int i = r0; i < r1; i += 2) {
-        if (i + 1 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 1) * ds.crp_pitch, N, lane, vec_ok, bufB);
-        SelectResult res = select_from_buf<EPL>(bufA, N, k, lane);
+    unsigned warm = 0;      // high word of the previous row's threshold (rows of T change slowly)
+    // One row buffer: with ~90 VGPRs five to six waves share a SIMD, and the row load of one wave hides
+    // behind the selection arithmetic of the others (a second, prefetched buffer costs more in occupancy
+    // than it gains: measured).
+    for (int i = r0; i < r1; i++) {
+        load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, bufA);
+        const SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, warm);
         store_uniform_select(k, N, thr + i, cut + i, res);
-        if (i + 1 < r1) {
-            if (i + 2 < r1) load_row_pairs<EPL>(base + (int64_t)(i + 2) * ds.crp_pitch, N, lane, vec_ok, bufA);
-            res = select_from_buf<EPL>(bufB, N, k, lane);
-            store_uniform_select(k, N, thr + i + 1, cut + i + 1, res);
-        }
     }
 }
 
@@ -424,16 +429,65 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
     int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)M) : (k_mode == 1 ? (int)kappa_k_fixed : M);
     SelectResult res;
     if (!trivial_select(k, M, res)) {
-        uint64_t key[EPL];
-        int idx[EPL];
+        if constexpr (EPL == 16) {
+            double x[16];
 #pragma unroll
-        for (int e = 0; e < EPL; e++) {
-            idx[e] = e * 64 + lane;
-            key[e] = idx[e] < M ? f64_key(colbuf[wave * ldc + idx[e]]) : ~0ull;
+            for (int e = 0; e < 16; e++) x[e] = colbuf[wave * ldc + min(e * 64 + lane, M - 1)] + 0.0;
+            unsigned cold = 0;
+            res = wave_select16(x, ColIdx{lane}, M, k, cold);
+        } else {
+            uint64_t key[EPL];
+            int idx[EPL];
+#pragma unroll
+            for (int e = 0; e < EPL; e++) {
+                idx[e] = e * 64 + lane;
+                key[e] = idx[e] < M ? f64_key(colbuf[wave * ldc + idx[e]]) : ~0ull;
+            }
+            res = wave_select_kth<EPL>(key, idx, M, k);
         }
-        res = wave_select_kth<EPL>(key, idx, M, k);
     }
     store_uniform_select(k, M, w.col_thr + (int64_t)p * w.max_n + j, w.col_cut + (int64_t)p * w.max_n + j, res);
+}
+
+// Fix-up pass of the 16-per-lane selection: one wave scans 64 thresholds of one pair; rows (DIR 0) or
+// columns (DIR 1) marked SELECT_UNRESOLVED are re-selected with the general key-array routine.  On real
+// data ~0.1 % of the rows are marked, so this kernel reads 4 bytes per row and returns.
+template <int DIR>
+__global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict__ S,
+                                                        const acoss_pair_desc *__restrict__ descs, int win,
+                                                        double kappa_k_fixed, int k_mode, ThreshWork w, int groups)
+{
+    const int p = blockIdx.x / groups, g = blockIdx.x % groups;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int count = DIR == 0 ? M : N;          // how many thresholds
+    const int len = DIR == 0 ? N : M;            // elements behind each
+    const int lane = threadIdx.x;
+    const int t = g * 64 + lane;
+    uint64_t *thr = (DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n);
+    int *cut = (DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n);
+    unsigned long long todo = __ballot(t < count && cut[t] == SELECT_UNRESOLVED);
+    if (todo == 0) return;
+    const int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)len) : (k_mode == 1 ? (int)kappa_k_fixed : len);
+    const double *base = S + ds.crp_off;
+    while (todo) {
+        const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
+        todo &= todo - 1;
+        uint64_t key[16];
+        int idx[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            idx[e] = e * 64 + lane;
+            const int q = min(idx[e], len - 1);
+            const double v = DIR == 0 ? base[(int64_t)which * ds.crp_pitch + q] : base[(int64_t)q * ds.crp_pitch + which];
+            key[e] = idx[e] < len ? f64_key(v) : ~0ull;
+        }
+        const SelectResult res = wave_select_kth<16>(key, idx, len, k);
+        if (lane == 0) {
+            thr[which] = res.thr_key;
+            cut[which] = res.cut;
+        }
+    }
 }
 
 // B[i][j] = row rule (and column rule when mutual).  A thread owns 4 adjacent columns (its column
@@ -679,6 +733,12 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
             hipLaunchKernelGGL((select_rows_kernel<32>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
         int rc = launch_check("select_rows_kernel");
         if (rc) return rc;
+        if (max_n <= 1024) {
+            const int groups = ceil_div(max_m, 64);
+            hipLaunchKernelGGL(select_fix_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, S, descs, win, kv, mode, w, groups);
+            rc = launch_check("select_fix_kernel<rows>");
+            if (rc) return rc;
+        }
     }
     if (mutual) {
         const int cb = ceil_div(max_n, SEL_COLS_PER_BLOCK);
@@ -693,6 +753,12 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
         }
         int rc = launch_check("select_cols_kernel");
         if (rc) return rc;
+        if (max_m <= 1024) {
+            const int groups = ceil_div(max_n, 64);
+            hipLaunchKernelGGL(select_fix_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, S, descs, win, kv, mode, w, groups);
+            rc = launch_check("select_fix_kernel<cols>");
+            if (rc) return rc;
+        }
     }
     return ACOSS_OK;
 }

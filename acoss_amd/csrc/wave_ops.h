@@ -175,4 +175,135 @@ __device__ inline SelectResult wave_select_kth(const uint64_t (&key)[EPL], const
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Faster selection for 16 elements per lane.  Counting "how many keys are below the probe" costs
+// 16 x (v_cmp + v_addc) = 32 half-rate VALU instructions per probe in wave_select_kth; here each lane
+// first sorts the high words of its 16 keys once (63-comparator odd-even merge network, v_min/v_max),
+// after which a probe is a 4-level binary search through v_cndmask trees (5 compares + 11 selects).
+// The search itself bisects a value bracket [L, U) with known counts and can be warm-started from the
+// threshold of the neighbouring row (rows of the windowed sums change slowly): it gallops outwards
+// from the previous threshold and bisects the last galloping interval, ~10 probes instead of ~19.
+// ---------------------------------------------------------------------------------------------
+__device__ inline void sort16_u32(unsigned (&s)[16])
+{
+    constexpr int net[63][2] = {
+        {0,1},{2,3},{0,2},{1,3},{1,2},{4,5},{6,7},{4,6},{5,7},{5,6},{0,4},{2,6},{2,4},{1,5},{3,7},{3,5},
+        {1,2},{3,4},{5,6},{8,9},{10,11},{8,10},{9,11},{9,10},{12,13},{14,15},{12,14},{13,15},{13,14},
+        {8,12},{10,14},{10,12},{9,13},{11,15},{11,13},{9,10},{11,12},{13,14},{0,8},{4,12},{4,8},{2,10},
+        {6,14},{6,10},{2,4},{6,8},{10,12},{1,9},{5,13},{5,9},{3,11},{7,15},{7,11},{3,5},{7,9},{11,13},
+        {1,2},{3,4},{5,6},{7,8},{9,10},{11,12},{13,14}};
+#pragma unroll
+    for (int c = 0; c < 63; c++) {
+        const unsigned a = s[net[c][0]], b = s[net[c][1]];
+        s[net[c][0]] = min(a, b);
+        s[net[c][1]] = max(a, b);
+    }
+}
+
+// number of entries of the ascending s[0..15] that are < cand
+__device__ inline int count_below_sorted16(const unsigned (&s)[16], unsigned cand)
+{
+    const bool b3 = s[7] < cand;
+    const unsigned t2 = b3 ? s[11] : s[3];
+    const bool b2 = t2 < cand;
+    const unsigned u0 = b2 ? s[5] : s[1], u1 = b2 ? s[13] : s[9];
+    const bool b1 = (b3 ? u1 : u0) < cand;
+    const unsigned w0 = b1 ? s[2] : s[0], w1 = b1 ? s[6] : s[4], w2 = b1 ? s[10] : s[8], w3 = b1 ? s[14] : s[12];
+    const unsigned x0 = b2 ? w1 : w0, x1 = b2 ? w3 : w2;
+    const bool b0 = (b3 ? x1 : x0) < cand;
+    return (b3 ? 8 : 0) + (b2 ? 4 : 0) + (b1 ? 2 : 0) + (b0 ? 1 : 0) + (s[15] < cand ? 1 : 0);
+}
+
+// order-preserving 32-bit halves of a float64's key (the value must already have -0.0 folded to +0.0)
+__device__ inline unsigned key_hi(double x)
+{
+    const unsigned h = (unsigned)__double2hiint(x);
+    return (h & 0x80000000u) ? ~h : (h | 0x80000000u);
+}
+__device__ inline unsigned key_lo(double x)
+{
+    const unsigned l = (unsigned)__double2loint(x);
+    return ((unsigned)__double2hiint(x) & 0x80000000u) ? ~l : l;
+}
+__device__ inline uint64_t key_of(double x) { return ((uint64_t)key_hi(x) << 32) | key_lo(x); }
+
+// element positions of the two register layouts used by the selection kernels
+struct RowIdx {   // rows: lane l holds elements 128*q + 2*l + {0,1}
+    int lane;
+    __device__ inline int operator()(int e) const { return 128 * (e >> 1) + 2 * lane + (e & 1); }
+};
+struct ColIdx {   // columns staged through LDS: element e of lane l is row e*64 + l
+    int lane;
+    __device__ inline int operator()(int e) const { return e * 64 + lane; }
+};
+
+// cut value with which wave_select16 marks a row it could not resolve on its fast path (several keys share
+// the winning high word, or exact ties): select_fix_kernel re-does those rows with wave_select_kth.
+constexpr int SELECT_UNRESOLVED = -2;
+
+// k-th smallest (1-based) of the n values a wave holds, 16 per lane (x[e] at position idx_of(e); positions
+// >= n are padding), ties cut lowest-position first, or cut == SELECT_UNRESOLVED (see above).  Works from the
+// raw values: the only arrays are x and the lane-sorted high words.  warm_hi: in = high word of a nearby threshold (0 = none), out = this one's.
+template <typename IdxFn>
+__device__ inline SelectResult wave_select16(const double (&x)[16], IdxFn idx_of, int n, int k, unsigned &warm_hi)
+{
+    unsigned s[16];
+    unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const bool valid = idx_of(e) < n;
+        const unsigned h = key_hi(x[e]);
+        s[e] = valid ? h : 0xffffffffu;
+        mn = min(mn, s[e]);
+        mx = max(mx, valid ? h : 0u);
+    }
+    sort16_u32(s);
+    mn = wave_umin(mn);
+    mx = wave_umax(mx);
+    // invariant: count(hi < L) = cL <= k-1 < cU = count(hi < U), the k-th smallest has hi in [L, U)
+    uint64_t L = mn, U = (uint64_t)mx + 1;
+    int cL = 0, cU = n;
+    auto probe = [&](const unsigned cand) {
+        const int c = wave_sum(count_below_sorted16(s, cand));
+        if (c <= k - 1) { L = cand; cL = c; } else { U = cand; cU = c; }
+        return c <= k - 1;
+    };
+    if (warm_hi > mn && warm_hi <= mx) {
+        // gallop away from the neighbouring threshold until the bracket closes on the other side
+        const bool right = probe(warm_hi);
+        uint64_t step = 1u << 11;
+        for (int g = 0; g < 24 && cU - cL > 1; g++) {
+            const uint64_t c64 = right ? (uint64_t)warm_hi + step : ((uint64_t)warm_hi > step ? (uint64_t)warm_hi - step : 0);
+            if (c64 <= L || c64 >= U) break;              // ran into the other end of the bracket
+            if (probe((unsigned)c64) != right) break;     // overshot: the answer is inside [L, U)
+            step <<= 1;
+        }
+    }
+    while (cU - cL > 1 && U - L > 1) probe((unsigned)(L + ((U - L) >> 1)));
+    if (cU - cL == 1) {
+        // the single element with hi in [L, U) is the k-th smallest
+        unsigned mh = 0, ml = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const unsigned h = key_hi(x[e]);
+            const bool in = ((uint64_t)h >= L) & ((uint64_t)h < U) & (idx_of(e) < n);
+            mh = max(mh, in ? h : 0u);
+            ml = max(ml, in ? key_lo(x[e]) : 0u);
+        }
+        SelectResult res;
+        res.cut = 0x7fffffff;
+        mh = wave_umax(mh);
+        res.thr_key = ((uint64_t)mh << 32) | wave_umax(ml);
+        warm_hi = mh;
+        return res;
+    }
+    // several keys share the high word L (or exact ties): left to the fix-up pass (~0.1 % of rows), so that
+    // the general routine's key arrays do not count against this kernel's registers
+    SelectResult res;
+    res.thr_key = 0;
+    res.cut = SELECT_UNRESOLVED;
+    warm_hi = (unsigned)L;
+    return res;
+}
+
 }  // namespace acoss
