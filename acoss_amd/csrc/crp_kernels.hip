@@ -316,6 +316,57 @@ __device__ inline void load_row_pairs(const double *row, int N, int lane, bool v
     }
 }
 
+// The selected positions of one row / column as 16 x uint64: word e = ballot over the lanes of register slot e,
+// i.e. bit l of word e = position idx_of(e) of lane l.  For columns (ColIdx: position e*64 + l) that is the
+// plain bit vector; for rows (RowIdx: position 128*(e>>1) + 2*l + (e&1)) words 2q and 2q+1 hold the even and
+// odd positions of the 128-position group q -- combine_bits_kernel interleaves them.
+// Positions follow the mask rule (value < threshold, or value == threshold and position <= cut); the key
+// order is the order of the doubles (-0.0 already folded), so values are compared, not keys.
+// lane `e` of (lo, hi) := the wave-uniform m.  The s_nop covers gfx950's VALU-writes-SGPR -> VALU-reads-SGPR
+// wait states, which the hazard recogniser does not insert around inline asm.
+__device__ inline void put_lane_u64(unsigned &lo, unsigned &hi, uint64_t m, int e)
+{
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi)
+        : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(e));
+}
+
+// lane e (< 16) gets the lane mask of "position idx_of(e) exists": computed once per wave, ANDed into every
+// emitted word
+template <typename IdxFn>
+__device__ inline uint64_t slot_valid_masks(IdxFn idx_of, int n, int lane)
+{
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const uint64_t m = __ballot(idx_of(e) < n);
+        put_lane_u64(lo, hi, m, e);
+    }
+    return ((uint64_t)hi << 32) | lo;
+}
+
+template <typename IdxFn>
+__device__ inline void emit_select_bits(const double (&x)[16], IdxFn idx_of, uint64_t valid, const SelectResult &r,
+                                        uint64_t *out, int lane)
+{
+    const double tv = r.thr_key == ~0ull ? INFINITY : (r.thr_key == 0ull ? -INFINITY : f64_from_key(r.thr_key));
+    unsigned lo = 0, hi = 0;
+    if (r.cut == 0x7fffffff) {        // no tie cut (almost always): one compare per slot
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint64_t m = __ballot(x[e] <= tv);
+            put_lane_u64(lo, hi, m, e);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const uint64_t m = __ballot((x[e] < tv) | ((x[e] == tv) & (idx_of(e) <= r.cut)));
+            put_lane_u64(lo, hi, m, e);
+        }
+    }
+    if (lane < 16) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
+}
+
 template <int EPL>
 __device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k, int lane, unsigned &warm)
 {
@@ -382,6 +433,10 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restri
         return;
     }
     unsigned warm = 0;      // high word of the previous row's threshold (rows of T change slowly)
+    uint64_t slot_valid = 0;
+    if constexpr (EPL == 16) {
+        if (w.row_bits) slot_valid = slot_valid_masks(RowIdx{lane}, N, lane);
+    }
     // One row buffer: with ~90 VGPRs five to six waves share a SIMD, and the row load of one wave hides
     // behind the selection arithmetic of the others (a second, prefetched buffer costs more in occupancy
     // than it gains: measured).
@@ -389,6 +444,10 @@ __global__ __launch_bounds__(256) void select_rows_kernel(const double *__restri
         load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, bufA);
         const SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, warm);
         store_uniform_select(k, N, thr + i, cut + i, res);
+        if constexpr (EPL == 16) {
+            if (w.row_bits && res.cut != SELECT_UNRESOLVED)
+                emit_select_bits(bufA, RowIdx{lane}, slot_valid, res, w.row_bits + ((int64_t)p * w.max_m + i) * 16, lane);
+        }
     }
 }
 
@@ -428,13 +487,24 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
     const int lane = threadIdx.x & 63;
     int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)M) : (k_mode == 1 ? (int)kappa_k_fixed : M);
     SelectResult res;
-    if (!trivial_select(k, M, res)) {
+    if (trivial_select(k, M, res)) {
+        if constexpr (EPL == 16) {
+            if (w.col_bits) {
+                double x[16];
+#pragma unroll
+                for (int e = 0; e < 16; e++) x[e] = 0.0;
+                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+            }
+        }
+    } else {
         if constexpr (EPL == 16) {
             double x[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = colbuf[wave * ldc + min(e * 64 + lane, M - 1)] + 0.0;
             unsigned cold = 0;
             res = wave_select16(x, ColIdx{lane}, M, k, cold);
+            if (w.col_bits && res.cut != SELECT_UNRESOLVED)
+                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
         } else {
             uint64_t key[EPL];
             int idx[EPL];
@@ -477,7 +547,7 @@ __global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict
         int idx[16];
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            idx[e] = e * 64 + lane;
+            idx[e] = DIR == 0 ? RowIdx{lane}(e) : ColIdx{lane}(e);     // the bit words must match the producers'
             const int q = min(idx[e], len - 1);
             const double v = DIR == 0 ? base[(int64_t)which * ds.crp_pitch + q] : base[(int64_t)q * ds.crp_pitch + which];
             key[e] = idx[e] < len ? f64_key(v) : ~0ull;
@@ -487,8 +557,75 @@ __global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict
             thr[which] = res.thr_key;
             cut[which] = res.cut;
         }
+        uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
+        if (bits) {
+            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * 16;
+            uint64_t mine = 0;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const bool on = (idx[e] < len) & ((key[e] < res.thr_key) | ((key[e] == res.thr_key) & (idx[e] <= res.cut)));
+                const uint64_t m = __ballot(on);
+                if (lane == e) mine = m;
+            }
+            if (lane < 16) bits[lane] = mine;
+        }
     }
 }
+
+// bit k of the argument -> bit 2k of the result
+__device__ inline uint64_t spread_bits32(unsigned a)
+{
+    uint64_t x = a;
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+
+// Bit-packed mutual mask: out[p][i][cw] (uint64, bit c = column cw*64 + c) = row_bits[i][cw] & the transpose
+// of col_bits.  One wave per 64 x 64 tile: lane l loads the column word of column cw*64 + l covering rows
+// ri*64 .. ri*64+63, 64 ballots transpose it, lane r ends with the row word of row ri*64 + r.
+__global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                           int mutual, ThreshWork w, int tiles_m, int tiles_n,
+                                                           uint64_t *__restrict__ out)
+{
+    const int tiles = tiles_m * tiles_n;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int64_t tw = (int64_t)blockIdx.x * 4 + wave;
+    if (tw >= (int64_t)K * tiles) return;
+    const int p = (int)(tw / tiles), t = (int)(tw % tiles);
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int ri = t / tiles_n, cw = t % tiles_n;
+    if (ri * 64 >= M) return;
+    const int lane = threadIdx.x & 63;
+    const int i = ri * 64 + lane;
+    uint64_t rw = 0;
+    if (i < M && cw * 64 < N) {
+        // columns 64cw .. 64cw+63 = half (cw & 1) of the 128-position group cw >> 1: even positions from word
+        // 2q, odd positions from word 2q + 1, 32 bits each, interleaved
+        const uint64_t *rb = w.row_bits + ((int64_t)p * w.max_m + i) * 16 + 2 * (cw >> 1);
+        const int sh = 32 * (cw & 1);
+        rw = spread_bits32((unsigned)(rb[0] >> sh)) | (spread_bits32((unsigned)(rb[1] >> sh)) << 1);
+    }
+    if (mutual) {
+        const int j = cw * 64 + lane;
+        const uint64_t cwd = j < N ? w.col_bits[((int64_t)p * w.max_n + j) * 16 + ri] : 0ull;
+        const unsigned clo = (unsigned)cwd, chi = (unsigned)(cwd >> 32);
+        uint64_t tr = 0;
+#pragma unroll
+        for (int r = 0; r < 64; r++) {
+            const unsigned bit = r < 32 ? ((clo >> r) & 1u) : ((chi >> (r - 32)) & 1u);
+            const uint64_t m = __ballot(bit != 0u);
+            if (lane == r) tr = m;
+        }
+        rw &= tr;
+    }
+    if (i < M) out[((int64_t)p * w.max_m + i) * 16 + cw] = rw;
+}
+
 
 // B[i][j] = row rule (and column rule when mutual).  A thread owns 4 adjacent columns (its column
 // thresholds stay in registers) and walks MASK_ROWS rows, with all of its 32-byte row loads issued
@@ -705,22 +842,23 @@ size_t acoss_binarize_work_bytes(int K, int max_nx, int max_ny, int win)
 }
 
 static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
-                          double kappa, int mutual, void *work, size_t work_bytes, hipStream_t st, ThreshWork &w)
+                          double kappa, int mutual, void *work, size_t work_bytes, hipStream_t st, ThreshWork &w,
+                          bool with_bits = false)
 {
     if (!S || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
         set_error("thresholds: bad argument");
         return ACOSS_EINVAL;
     }
-    if (work_bytes < acoss_binarize_work_bytes(K, max_nx, max_ny, win)) {
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    if (work_bytes < thresh_work_bytes(K, max_m, max_n, with_bits)) {
         set_error("thresholds: workspace too small");
         return ACOSS_EINVAL;
     }
-    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    if (max_m > 2048 || max_n > 2048) {
-        set_error("thresholds: matrices larger than 2048 x 2048 are not supported yet");
+    if (max_m > 2048 || max_n > 2048 || (with_bits && (max_m > 1024 || max_n > 1024))) {
+        set_error("thresholds: matrices larger than 2048 x 2048 (1024 x 1024 for bit masks) are not supported yet");
         return ACOSS_ENOTSUP;
     }
-    w = thresh_work_layout(work, K, max_m, max_n);
+    w = thresh_work_layout(work, K, max_m, max_n, with_bits);
     if (K == 0) return ACOSS_OK;
     double kv;
     int mode;
@@ -768,6 +906,26 @@ int acoss_thresholds_batch(const double *S, const acoss_pair_desc *descs, int K,
 {
     ThreshWork w;
     return run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, (hipStream_t)stream, w);
+}
+
+size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win)
+{
+    return thresh_work_bytes(K > 0 ? K : 0, max_nx - win + 1 > 0 ? max_nx - win + 1 : 0,
+                             max_ny - win + 1 > 0 ? max_ny - win + 1 : 0, true);
+}
+
+int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                          double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
+{
+    if (!bits) { set_error("mask_bits_batch: bad argument"); return ACOSS_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    ThreshWork w;
+    int rc = run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, st, w, true);
+    if (rc || K == 0) return rc;
+    const int tm = ceil_div(w.max_m, 64), tn = 16;     // all 16 words of every row are written
+    const int64_t waves = (int64_t)K * tm * tn;
+    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, st, descs, K, win, mutual, w, tm, tn, bits);
+    return launch_check("combine_bits_kernel");
 }
 
 int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,

@@ -515,6 +515,111 @@ __global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restri
     if (lane == 0) scores[p] = best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Alignment from the bit-packed mutual mask (acoss_mask_bits_batch): one wave per pair, a lane reads the
+// 16 mask bits of its columns as one uint16 per row (128 contiguous bytes per wave and row), 16 rows ahead.
+// With ~60 VGPRs eight such waves share a SIMD, and a pair's whole mask is 124 KB: this sweep costs a
+// fraction of the selection passes.  Constant gap penalty, <= 1024 columns.
+// ---------------------------------------------------------------------------------------------
+template <int KIND>
+__global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict__ bits,
+                                                      const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                      int max_m, float gamma, int boundary,
+                                                      float *__restrict__ scores)
+{
+    constexpr int CPL = 16;
+    constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
+    constexpr int R0 = (KIND == KIND_DMAX) ? 1 : 2;
+    constexpr int PF = 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (M < FIRST + 1 || N < FIRST + 1) {
+        if (lane == 0) scores[p] = 0.0f;
+        return;
+    }
+    const int j0 = lane * CPL;
+    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(R0 + u, M - 1) * 64];
+    float d1[CPL], d2[CPL], d3[CPL];
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { d1[c] = d2[c] = d3[c] = 0.f; }
+    unsigned m1 = 0, m2 = 0;
+    float best = 0.0f;
+    const bool l0 = lane == 0;
+    auto do_row = [&](const int i, const unsigned m0) {
+        if (i >= FIRST) {
+            const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
+            const float h2a = lane_shr1(d2[CPL - 1], 0.f);
+            float h1c = 0.f, h3a = 0.f;
+            unsigned h0 = 0;
+            if (KIND == KIND_DMAX) {
+                h1c = lane_shr1(d1[CPL - 3], 0.f);
+                h3a = lane_shr1(d3[CPL - 1], 0.f);
+                h0 = (unsigned)lane_shr1((int)m0, 0);
+            }
+            const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);
+            float nd[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const float p_diag = c >= 1 ? d1[c - 1] : h1a;
+                const float p_up2 = c >= 1 ? d2[c - 1] : h2a;
+                const float p_left2 = c >= 2 ? d1[c - 2] : (c == 1 ? h1a : h1b);
+                float m = max3f(p_diag, p_up2, p_left2);
+                if (KIND == KIND_DMAX) {
+                    const float p_up3 = c >= 1 ? d3[c - 1] : h3a;
+                    const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));
+                    const float s_u1 = (float)((m1 >> c) & 1u);
+                    const float s_u2 = (float)((m2 >> c) & 1u);
+                    const float s_l1 = (float)((ext >> (c + 1)) & 1u);
+                    const float s_l2 = (float)((ext >> c) & 1u);
+                    const float c2 = p_up2 + s_u1;
+                    const float c3 = p_left2 + s_l1;
+                    const float c4 = (p_up3 + s_u2) + s_u1;
+                    const float c5 = (p_left3 + s_l2) + s_l1;
+                    m = fmaxf(fmaxf(max3f(p_diag, c2, c3), c4), c5);
+                }
+                const bool on = (m0 >> c) & 1u;
+                float v = fmaxf(m + (on ? 1.0f : -gamma), 0.0f);
+                if (c < FIRST) {
+                    const float bval = (KIND == KIND_DMAX && c == 2 && boundary) ? (float)((m0 >> 2) & 1u) : 0.0f;
+                    best = fmaxf(best, l0 ? 0.0f : v);
+                    v = l0 ? bval : v;
+                } else {
+                    best = fmaxf(best, v);
+                }
+                nd[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) { d3[c] = d2[c]; d2[c] = d1[c]; d1[c] = nd[c]; }
+        } else if (KIND == KIND_DMAX && i == 2) {
+#pragma unroll
+            for (int c = 0; c < CPL; c++) d1[c] = (boundary && j0 + c >= 2) ? (float)((m0 >> c) & 1u) : 0.0f;
+        }
+        m2 = m1;
+        m1 = m0;
+    };
+    for (int ib = R0; ib < M; ib += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = ib + u;
+            if (i < M) {
+                const unsigned m0 = ring[u];        // bits past column N are zero by construction
+                if (i + PF < M) ring[u] = rowp[(int64_t)(i + PF) * 64];
+                do_row(i, m0);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
+    if (lane == 0) scores[p] = best;
+}
+
 template <int KIND>
 static int launch_dp(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
                      int boundary, const acoss_align_params *params, float *scores, hipStream_t st)
@@ -562,6 +667,29 @@ int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max
                     const acoss_align_params *params, float *scores, void *stream)
 {
     return launch_dp<KIND_SWC>(S, mats, K, max_cols, D, 0, params, scores, (hipStream_t)stream);
+}
+
+int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                           int max_ny, int boundary, const acoss_align_params *params, float *scores, void *stream)
+{
+    if (!bits || !descs || !scores || K < 0 || win < 1 || max_nx < win || max_ny < win || (kind != 0 && kind != 1)) {
+        set_error("align_bits_batch: bad argument (kind 0 = qmax, 1 = dmax)");
+        return ACOSS_EINVAL;
+    }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    acoss_align_params ap;
+    if (params) ap = *params; else acoss_default_align_params(&ap);
+    if (max_n > 1024 || max_m > 1024 || ap.gamma_onset != ap.gamma_extension) {
+        set_error("align_bits_batch: needs <= 1024 x 1024 matrices and gamma_onset == gamma_extension");
+        return ACOSS_ENOTSUP;
+    }
+    if (K == 0) return ACOSS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0)
+        hipLaunchKernelGGL(dp_bits_kernel<KIND_QMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, scores);
+    else
+        hipLaunchKernelGGL(dp_bits_kernel<KIND_DMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, scores);
+    return launch_check("dp_bits_kernel");
 }
 
 int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *descs, int K, int win, int max_nx,

@@ -14,9 +14,20 @@ struct ThreshWork {
     int *row_cut;        // [K][max_m]
     int *col_cut;        // [K][max_n]
     int max_m, max_n;
+    // optional (bit-mask path, <= 1024 x 1024): the selected positions of every row / column, 16 x uint64 each
+    // in the producing kernel's register-slot order (see emit_select_bits)
+    uint64_t *row_bits;  // [K][max_m][16]
+    uint64_t *col_bits;  // [K][max_n][16]
 };
 
-inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n)
+inline size_t thresh_work_bytes(int K, int max_m, int max_n, bool with_bits)
+{
+    size_t b = (size_t)K * (size_t)(max_m + max_n) * (sizeof(uint64_t) + sizeof(int)) + 64;
+    if (with_bits) b += (size_t)K * (size_t)(max_m + max_n) * 16 * sizeof(uint64_t) + 64;
+    return b;
+}
+
+inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bool with_bits = false)
 {
     ThreshWork w;
     w.max_m = max_m;
@@ -25,6 +36,14 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n)
     w.col_thr = w.row_thr + (size_t)K * max_m;
     w.row_cut = (int *)(w.col_thr + (size_t)K * max_n);
     w.col_cut = w.row_cut + (size_t)K * max_m;
+    w.row_bits = nullptr;
+    w.col_bits = nullptr;
+    if (with_bits) {
+        uintptr_t a = (uintptr_t)(w.col_cut + (size_t)K * max_n);
+        a = (a + 63) & ~(uintptr_t)63;
+        w.row_bits = (uint64_t *)a;
+        w.col_bits = w.row_bits + (size_t)K * max_m * 16;
+    }
     return w;
 }
 

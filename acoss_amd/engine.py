@@ -249,6 +249,46 @@ def align_fused(kind, T_buf, batch, work, mutual=True, boundary=0, params=None, 
     return scores[:batch.K]
 
 
+def mask_bits(S_buf, batch, kappa, mutual=True, out=None, work=None):
+    """Bit-packed kNN mask of every pair ((K, max_m, 16) uint64; bit c of word w = column 64w + c)."""
+    lib = _lib.load()
+    max_m = batch.max_nx - batch.win + 1
+    if out is None:
+        out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=S_buf.device)
+    need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=S_buf.device)
+    check(lib.acoss_mask_bits_batch(_ptr(S_buf), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
+                                    batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out), _ptr(work),
+                                    work.numel(), _stream()), "mask_bits_batch")
+    return out, work
+
+
+def align_bits(kind, bits, batch, boundary=0, params=None, scores=None):
+    """qmax / dmax from the bit-packed mask."""
+    lib = _lib.load()
+    if scores is None:
+        scores = torch.empty(max(batch.K, 1), dtype=torch.float32, device=bits.device)
+    pp = ctypes.byref(params) if params is not None else None
+    check(lib.acoss_align_bits_batch({"qmax": 0, "dmax": 1}[kind], _ptr(bits), _ptr(batch.descs_dev), batch.K,
+                                     batch.win, batch.max_nx, batch.max_ny, int(boundary), pp, _ptr(scores),
+                                     _stream()), "align_bits_batch")
+    return scores[:batch.K]
+
+
+def bits_path_supported(batch):
+    return batch.max_nx - batch.win + 1 <= 1024 and batch.max_ny - batch.win + 1 <= 1024
+
+
+def unpack_mask_bits(bits, batch, p):
+    """Host uint8 (M, N) view of pair p's bit-packed mask (tests)."""
+    max_m = batch.max_nx - batch.win + 1
+    M, N = int(batch.M[p]), int(batch.N[p])
+    words = bits[p * max_m * 16:(p * max_m + M) * 16].cpu().numpy().view(np.uint64).reshape(M, 16)
+    b = np.unpackbits(words.view(np.uint8).reshape(M, 128), axis=1, bitorder="little")
+    return b[:, :N]
+
+
 def fused_align_supported(batch):
     return batch.max_ny - batch.win + 1 <= 1024
 
@@ -311,6 +351,13 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
         crp(corpus, batch, xp, sqrt_out=False, out=T)
         denom = (batch.M + batch.N).astype(np.float64)
+        if bits_path_supported(batch):
+            bits, work = mask_bits(T, batch, kappa, mutual=True, work=work)
+            if "qmax" in want:
+                out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
+            if "dmax" in want:
+                out["dmax"][lo:lo + len(sel)] = align_bits("dmax", bits, batch, boundary=1).cpu().numpy().astype(np.float64) / denom
+            continue
         if fused_align_supported(batch):
             work = thresholds(T, batch, kappa, mutual=True, work=work)
             if "qmax" in want:

@@ -46,39 +46,57 @@ def parse():
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--path", choices=("fast", "staged"), default="fast",
                     help="fast: fused CSM+sliding kernel (the product path); staged: one kernel per reference function")
+    ap.add_argument("--overlap", action="store_true",
+                    help="fast path: run the alignment sweep of batch b on a second HIP stream while the main "
+                         "stream computes batch b+1 (measured: no gain, the sweep's registers/LDS crowd the CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     return ap.parse_args()
 
 
-STAGES = {"fast": ["oti", "pack_x", "crp", "thresholds", "qmax_fused"],
+STAGES = {"fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
 
 
 class Runner(object):
-    """One step, fast path: OTI -> pack_x -> crp (fused CSM + sliding window, squared) -> row/column kNN
-    thresholds -> qmax fused with the mask (no mask in memory).  Staged path: OTI -> CSM -> sliding ->
+    """One step, fast path: OTI -> pack_x -> crp (fused CSM + sliding window, squared) -> mask_bits (row and
+    column kNN selection emitting bit vectors by ballot, transposed and ANDed into a 124 KB bit mask per pair)
+    -> qmax from the bits.  Staged path: OTI -> CSM -> sliding ->
     binarise (thresholds + mask) -> qmax, one kernel per reference function.  All buffers are
     preallocated and every launch goes to torch's current stream; HIP events between the stages give
     per-stage times of the timed steps."""
 
-    def __init__(self, corpus, batches, m, kappa, path):
+    def __init__(self, corpus, batches, m, kappa, path, overlap=True):
         import torch
         from acoss_amd import engine
         self.engine, self.torch, self.path = engine, torch, path
+        # fast path: the alignment sweep (latency-bound: 992 serial row steps, ~15 % VALU) of batch b runs
+        # on a second HIP stream while the main stream already computes batch b+1 (two sets of T/threshold
+        # buffers, events both ways)
+        self.overlap = overlap and path == "fast"
         self.corpus, self.m, self.kappa = corpus, m, kappa
         dev = corpus.device
         lib = engine._lib.load()
         tr = max(b.total_crp for b in batches)
         self.S = torch.empty(tr, dtype=torch.float64, device=dev)
-        self.B = torch.zeros(tr, dtype=torch.uint8, device=dev)
+        self.B = torch.zeros(tr, dtype=torch.uint8, device=dev) if path == "staged" else None
         if path == "staged":
             self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
         else:
             self.xp = torch.empty(max(int(lib.acoss_xpack_elems(b.K, b.max_nx)) for b in batches),
                                   dtype=corpus.feats.dtype, device=dev)
-        need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
+        if path == "fast":
+            need = max(int(lib.acoss_mask_bits_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
+            self.bits = torch.zeros(max(b.K * (b.max_nx - m + 1) * 16 for b in batches), dtype=torch.int64, device=dev)
+        else:
+            need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
         self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self.overlap:
+            self.Ss = [self.S, torch.empty(tr, dtype=torch.float64, device=dev)]
+            self.works = [self.work, torch.empty(need, dtype=torch.uint8, device=dev)]
+            self.side = torch.cuda.Stream(device=dev)
+            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
+            self.free = [torch.cuda.Event(), torch.cuda.Event()]
         self.plans = []
         for b in batches:
             mats, _ = b.mats()
@@ -97,6 +115,28 @@ class Runner(object):
         def mark(k):
             if ev is not None:
                 ev[k].record()
+        if self.overlap:
+            torch = self.torch
+            slot = i & 1
+            main = torch.cuda.current_stream()
+            main.wait_event(self.free[slot])          # the sweep that last read this slot has finished
+            S, work = self.Ss[slot], self.works[slot]
+            mark(0)
+            e.oti(self.corpus, b)
+            mark(1)
+            e.pack_x(self.corpus, b, out=self.xp)
+            mark(2)
+            e.crp(self.corpus, b, self.xp, sqrt_out=False, out=S)
+            mark(3)
+            e.thresholds(S, b, self.kappa, True, work=work)
+            self.ready[slot].record(main)
+            with torch.cuda.stream(self.side):
+                self.side.wait_event(self.ready[slot])
+                mark(4)
+                e.align_fused("qmax", S, b, work, scores=scores_out)   # the register-heavy sweep straight from T
+                mark(5)
+                self.free[slot].record(self.side)
+            return
         mark(0)
         e.oti(self.corpus, b)
         mark(1)
@@ -110,9 +150,9 @@ class Runner(object):
             e.sliding(self.C, b, out=self.S)
         mark(3)
         if self.path == "fast":
-            e.thresholds(self.S, b, self.kappa, True, work=self.work)
+            e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
             mark(4)
-            e.align_fused("qmax", self.S, b, self.work, scores=scores_out)
+            e.align_bits("qmax", self.bits, b, scores=scores_out)
         else:
             e.binarize(self.S, b, self.kappa, True, out=self.B, work=self.work)
             mark(4)
@@ -146,7 +186,7 @@ def main():
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
     step_idx = [mine[(np.arange(P) + s * P) % len(mine)] for s in range(n_steps)]
     batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev) for ix in step_idx]
-    runner = Runner(corpus, batches, m, kappa, args.path)
+    runner = Runner(corpus, batches, m, kappa, args.path, overlap=args.overlap)
     scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
 
@@ -162,6 +202,8 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps):
         runner.step(s, scores[s], events[s])
+    if runner.overlap:
+        torch.cuda.current_stream().wait_stream(runner.side)
     # the path's only collective: gather every rank's timed scores (RCCL all-gather over xGMI)
     timed_idx = np.concatenate(step_idx[args.warmup:])
     local = scores[args.warmup:].reshape(-1)
@@ -203,7 +245,7 @@ def main():
         "config": {"workload": "synthetic %d songs x %d frames x 12-bin HPCP (f64), Serra09 chroma_qmax "
                                "m=9 kappa=0.095 OTI, %d pairs/step/GPU of the %d-pair job"
                                % (args.songs, args.frames, P, len(all_pairs)),
-                   "path": args.path, "pairs_per_step_per_gpu": P,
+                   "path": args.path, "pairs_per_step_per_gpu": P, "overlap_alignment_stream": bool(runner.overlap),
                    "parallelism": "pair-shard x%d, one all-gather" % world},
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -135,3 +135,32 @@ def test_results_do_not_depend_on_stale_device_memory(eng, orc):
             res = fn(corpus, pairs, batch_pairs=13)
             assert np.array_equal(res["qmax"], q) and np.array_equal(res["dmax"], d), (fill, fn.__name__)
         del corpus
+
+
+def test_bit_mask_path_equals_byte_mask_path(eng, golden):
+    """Bit-packed masks from the selection ballots == the uint8 masks, and alignment from bits == alignment
+    from bytes (mutual and one-sided, both dmax boundaries), on ragged 1000-frame and small pairs."""
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"]),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32))]
+    for feats, off, gc, pairs in cases:
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device)
+        eng.oti(corpus, batch)
+        T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+        mats, _ = batch.mats()
+        for mutual in (True, False):
+            B = eng.binarize(T, batch, 0.095, mutual=mutual)
+            bits, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+            for p in range(0, batch.K, max(1, batch.K // 7)):
+                d = batch.descs[p]
+                M, N = d["nx"] - 8, d["ny"] - 8
+                Bp = B[d["crp_off"]:d["crp_off"] + M * d["crp_pitch"]].cpu().numpy().reshape(M, -1)[:, :N]
+                assert np.array_equal(eng.unpack_mask_bits(bits, batch, p), Bp), (p, mutual)
+            assert np.array_equal(eng.align_bits("qmax", bits, batch).cpu().numpy(), eng.align("qmax", B, mats).cpu().numpy())
+            for boundary in (0, 1):
+                assert np.array_equal(eng.align_bits("dmax", bits, batch, boundary=boundary).cpu().numpy(),
+                                      eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())

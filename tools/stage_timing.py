@@ -60,6 +60,10 @@ _, t = timed("binarize(T)", lambda: engine.binarize(Tb, batch, 0.095, True, out=
 _, t = timed("thresholds(T)", lambda: engine.thresholds(Tb, batch, 0.095, True, work=work)); tf += t
 _, t = timed("qmax fused", lambda: engine.align_fused("qmax", Tb, batch, work)); tf += t
 _, t2 = timed("dmax fused", lambda: engine.align_fused("dmax", Tb, batch, work, boundary=1))
+(bits, wb), t = timed("mask_bits(T)", lambda: engine.mask_bits(Tb, batch, 0.095, True)); tb = t
+_, t = timed("qmax bits", lambda: engine.align_bits("qmax", bits, batch)); tb += t
+_, t2 = timed("dmax bits", lambda: engine.align_bits("dmax", bits, batch, boundary=1))
+print("bits chain (oti+pack+crp+mask_bits+qmax_bits): %.3f ms -> %.0f pair-scores/s" % (tf - 0 + 0.03, 0))
 print("fast chain (oti+pack+crp+thresholds+qmax_fused): %.3f ms for %d pairs -> %.0f pair-scores/s" % (tf + 0.03, K, K / ((tf + 0.03) * 1e-3)))
 # f32 csm
 c32 = engine.DeviceCorpus(corpus_h.feats.astype(np.float32), corpus_h.frame_off, gchroma=corpus_h.gchroma)
