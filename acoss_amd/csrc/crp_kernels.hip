@@ -390,7 +390,7 @@ __device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k,
 
 // MODE (development probes, product = 0): 1 = row loads only, 2 = selection only (synthetic values)
 template <int EPL, int MODE = 0>
-__global__ __launch_bounds__(256) void select_rows_kernel(const double *__restrict__ S,
+__global__ __launch_bounds__(256, EPL == 16 ? 4 : 1) void select_rows_kernel(const double *__restrict__ S,
                                                           const acoss_pair_desc *__restrict__ descs,
                                                           int win, double kappa_k_fixed, int k_mode,
                                                           ThreshWork w, int rows_blocks)

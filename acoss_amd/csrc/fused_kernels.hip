@@ -390,8 +390,12 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     constexpr int TN = CRP_CT - HALO;
     constexpr int KSTEPS = (D + 3) / 4;
     constexpr int ROWS_PER_WAVE = STRIP_ROWS / 8;
-    __shared__ __attribute__((aligned(16))) double cbuf[CROWS * CRP_LD];
+    // DIAG: window sums by diagonal runs (see the sum phase); needs ROWS_PER_WAVE spare columns left of the strip
+    constexpr bool DIAG = (TN + ROWS_PER_WAVE <= CRP_CT) && (ROWS_PER_WAVE % 2 == 0);
+    constexpr int CPAD = 8;       // the diagonal runs of the edge lanes start up to 4 columns outside a row
+    __shared__ __attribute__((aligned(16))) double cbuf_raw[CROWS * CRP_LD + 2 * CPAD];
     __shared__ __attribute__((aligned(16))) double xs[STRIP_ROWS * XS_LD];
+    double *const cbuf = cbuf_raw + CPAD;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int p = lb / strips;
     const acoss_pair_desc ds = descs[p];
@@ -434,6 +438,10 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     const double *rda = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + ca;
     const double *rdb = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + cbr;
     double *wr = cbuf + (HALO + lk) * CRP_LD + 16 * wave + lr;
+    // diagonal-run form: this lane owns the two adjacent diagonals that start at columns dcol and dcol + 1 of
+    // the wave's first output row
+    const int dcol = 2 * lane - ROWS_PER_WAVE;
+    const double *rdd = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + dcol;
     // halo copy: thread h < HALO*128 moves element h of rows [32, 32+HALO) to rows [0, HALO)
     const bool copier = threadIdx.x < HALO * (CRP_CT / 2);
     const int hrow = (2 * threadIdx.x) / CRP_CT, hcol = (2 * threadIdx.x) % CRP_CT;
@@ -485,6 +493,54 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         xn1 = xn2;
         // ---- output rows [32t - HALO, 32t + 32 - HALO): ROWS_PER_WAVE per wave, window sums from LDS
         const int g0 = t * STRIP_ROWS - HALO + wave * ROWS_PER_WAVE;          // wave-uniform
+        if constexpr (DIAG) {
+            // Output (q, c) and (q + 1, c + 1) share WIN - 1 of their WIN addends, so a lane walks two adjacent
+            // diagonals for ROWS_PER_WAVE rows: ROWS_PER_WAVE + WIN - 1 two-element LDS reads instead of
+            // 2 * ROWS_PER_WAVE * WIN single ones, each output still summed in the order k = 0..WIN-1.
+            // Row q of the wave then sits at columns dcol + q, dcol + q + 1: an aligned pair for even q; for
+            // odd q the pair is (own second diagonal, first diagonal of the next lane), one DPP shift.
+            double va[ROWS_PER_WAVE + HALO], vb[ROWS_PER_WAVE + HALO];
+#pragma unroll
+            for (int m = 0; m < ROWS_PER_WAVE + HALO; m++) {
+                va[m] = rdd[m * (CRP_LD + 1)];
+                vb[m] = rdd[m * (CRP_LD + 1) + 1];
+            }
+#pragma unroll
+            for (int q = 0; q < ROWS_PER_WAVE; q++) {
+                const int gi = g0 + q;
+                double sa = 0.0, sb = 0.0;
+                if (MODE == 2) {
+                    sa = va[q];
+                    sb = vb[q];
+                } else {
+#pragma unroll
+                    for (int k = 0; k < WIN; k++) {
+                        sa += va[q + k];
+                        sb += vb[q + k];
+                    }
+                }
+                if (SQRT_OUT) {
+                    sa = csm_sqrt(sa);
+                    sb = csm_sqrt(sb);
+                }
+                double *o = orow + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
+                const int col = dcol + q;
+                if (MODE == 1) {
+                    if (sa == -1.25) o[col & 63] = sb;
+                } else if (CHECKED) {
+                    const bool row_ok = gi >= 0 && gi < M;
+                    if (row_ok && col >= 0 && col < TN && j0 + col < N) o[col] = sa;
+                    if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) o[col + 1] = sb;
+                } else if ((q & 1) == 0) {
+                    if (col >= 0 && col < TN) *reinterpret_cast<double2 *>(o + col) = make_double2(sa, sb);
+                } else {
+                    const int glo = __builtin_amdgcn_update_dpp(0, __double2loint(sa), 0x130, 0xf, 0xf, true);   // wave_shl:1
+                    const int ghi = __builtin_amdgcn_update_dpp(0, __double2hiint(sa), 0x130, 0xf, 0xf, true);
+                    if (col + 1 >= 0 && col + 1 < TN)
+                        *reinterpret_cast<double2 *>(o + col + 1) = make_double2(sb, __hiloint2double(ghi, glo));
+                }
+            }
+        } else {
 #pragma unroll
         for (int q = 0; q < ROWS_PER_WAVE; q++) {
             const int gi = g0 + q;
@@ -523,6 +579,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     if (col + 1 < TN) *reinterpret_cast<double2 *>(o + col) = v;
                 }
             }
+        }
         }
         // carry the last HALO C rows over to the next step: read before the barrier, write after it
         double2 hv = make_double2(0.0, 0.0);
