@@ -316,6 +316,24 @@ __device__ inline void load_row_pairs(const double *row, int N, int lane, bool v
     }
 }
 
+// 16-per-lane form: lane l holds positions e*64 + l (8-byte loads, 512 contiguous bytes per instruction), so
+// the elements of a lane are 64 positions apart -- neighbouring, strongly correlated values sit in different
+// lanes, which the histogram selection wants (one candidate per lane), and the bit words come out as the plain
+// bit vector of the row.
+__device__ inline void load_row_strided(const double *row, int N, int lane, double (&buf)[16])
+{
+    // unsigned 32-bit element offsets from the wave-uniform row pointer: SGPR base + one offset VGPR (+ immediates)
+    // instead of sixteen 64-bit address pairs
+    if (N > 15 * 64) {      // wave-uniform: only the last slot can run past the row
+#pragma unroll
+        for (int e = 0; e < 15; e++) buf[e] = row[(unsigned)(e * 64 + lane)];
+        buf[15] = row[(unsigned)min(15 * 64 + lane, N - 1)];
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; e++) buf[e] = row[(unsigned)min(e * 64 + lane, N - 1)];
+    }
+}
+
 // The selected positions of one row / column as 16 x uint64: word e = ballot over the lanes of register slot e,
 // i.e. bit l of word e = position idx_of(e) of lane l.  For columns (ColIdx: position e*64 + l) that is the
 // plain bit vector; for rows (RowIdx: position 128*(e>>1) + 2*l + (e&1)) words 2q and 2q+1 hold the even and
@@ -367,15 +385,17 @@ __device__ inline void emit_select_bits(const double (&x)[16], IdxFn idx_of, uin
     if (lane < 16) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
 }
 
-template <int EPL>
-__device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k, int lane, unsigned &warm)
+template <int EPL, bool HIST = false>
+__device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k, int lane, unsigned &warm,
+                                               unsigned *hist, HistWarm &hwarm)
 {
     SelectResult res;
     if (trivial_select(k, N, res)) return res;
 #pragma unroll
     for (int e = 0; e < EPL; e++) buf[e] = buf[e] + 0.0;     // -0.0 -> +0.0
     if constexpr (EPL == 16) {
-        return wave_select16(buf, RowIdx{lane}, N, k, warm);
+        if constexpr (HIST) return wave_select16_hist(buf, ColIdx{lane}, N, k, hist, lane, hwarm);
+        else return wave_select16(buf, ColIdx{lane}, N, k, warm);
     } else {
         uint64_t key[EPL];
         int idx[EPL];
@@ -388,7 +408,8 @@ __device__ inline SelectResult select_from_buf(double (&buf)[EPL], int N, int k,
     }
 }
 
-// MODE (development probes, product = 0): 1 = row loads only, 2 = selection only (synthetic values)
+// MODE (development probes, product = 0): 1 = row loads only, 2 = selection only (synthetic values),
+// 3 = the sorted / probing selection instead of the histogram one
 template <int EPL, int MODE = 0>
 __global__ __launch_bounds__(256, EPL == 16 ? 4 : 1) void select_rows_kernel(const double *__restrict__ S,
                                                           const acoss_pair_desc *__restrict__ descs,
@@ -427,34 +448,47 @@ __global__ __launch_bounds__(256, EPL == 16 ? 4 : 1) void select_rows_kernel(con
 #pragma unroll
             for (int e = 0; e < EPL; e++) bufA[e] = (double)((lane * 2654435761u + e * 40503u + i * 97u) & 0xfffff) * 1e-3 + 0.5;
             unsigned cold = 0;
-            SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, cold);
+            HistWarm nohw{0, HIST_WARM_SHIFT0};
+            SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, cold, nullptr, nohw);
             store_uniform_select(k, N, thr + i, cut + i, res);
         }
         return;
     }
     unsigned warm = 0;      // high word of the previous row's threshold (rows of T change slowly)
+    constexpr bool HIST = (EPL == 16) && (MODE == 0);
+    __shared__ __attribute__((aligned(16))) unsigned hist_all[HIST ? 4 * HIST_WORDS : 4];
+    unsigned *hist = hist_all + (HIST ? wave * HIST_WORDS : 0);
+    if constexpr (HIST) hist_clear(hist, lane);
+    HistWarm hwarm{0, HIST_WARM_SHIFT0};
     uint64_t slot_valid = 0;
     if constexpr (EPL == 16) {
-        if (w.row_bits) slot_valid = slot_valid_masks(RowIdx{lane}, N, lane);
+        if (w.row_bits) slot_valid = slot_valid_masks(ColIdx{lane}, N, lane);
     }
-    // One row buffer: with ~90 VGPRs five to six waves share a SIMD, and the row load of one wave hides
-    // behind the selection arithmetic of the others (a second, prefetched buffer costs more in occupancy
-    // than it gains: measured).
-    for (int i = r0; i < r1; i++) {
-        load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, bufA);
-        const SelectResult res = select_from_buf<EPL>(bufA, N, k, lane, warm);
+    auto load = [&](double (&buf)[EPL], const int i) {
+        if constexpr (EPL == 16) load_row_strided(base + (int64_t)i * ds.crp_pitch, N, lane, buf);
+        else load_row_pairs<EPL>(base + (int64_t)i * ds.crp_pitch, N, lane, vec_ok, buf);
+    };
+    auto process = [&](double (&buf)[EPL], const int i) {
+        const SelectResult res = select_from_buf<EPL, HIST>(buf, N, k, lane, warm, hist, hwarm);
         store_uniform_select(k, N, thr + i, cut + i, res);
         if constexpr (EPL == 16) {
             if (w.row_bits && res.cut != SELECT_UNRESOLVED)
-                emit_select_bits(bufA, RowIdx{lane}, slot_valid, res, w.row_bits + ((int64_t)p * w.max_m + i) * 16, lane);
+                emit_select_bits(buf, ColIdx{lane}, slot_valid, res, w.row_bits + ((int64_t)p * w.max_m + i) * 16, lane);
         }
+    };
+    // One row buffer: a second, prefetched buffer costs more registers (occupancy / spills) than it gains,
+    // with either selection (measured).  The kernel runs at ~75 % of its load-only time.
+    for (int i = r0; i < r1; i++) {
+        load(bufA, i);
+        process(bufA, i);
     }
 }
 
-constexpr int SEL_COLS_PER_BLOCK = 8;
+constexpr int SEL_COLS_PER_BLOCK = 8;       // = waves per block; 64-byte row segments (4 columns / block: loads alone 4.4 ms)
+constexpr int SEL_COLS_THREADS = SEL_COLS_PER_BLOCK * 64;
 
-template <int EPL>
-__global__ __launch_bounds__(512) void select_cols_kernel(const double *__restrict__ S,
+template <int EPL, int MODE = 0>
+__global__ __launch_bounds__(SEL_COLS_THREADS, 4) void select_cols_kernel(const double *__restrict__ S,
                                                           const acoss_pair_desc *__restrict__ descs,
                                                           int win, double kappa_k_fixed, int k_mode,
                                                           ThreshWork w, int col_blocks)
@@ -472,7 +506,7 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
     // 512 threads: 64 rows x 8 columns per sweep, 64-byte segments per row.  Fully unrolled and
     // branch-free (clamped addresses) so that all EPL loads of a thread are in flight together.
     {
-        const int c = threadIdx.x & 7, rr = threadIdx.x >> 3;
+        const int c = threadIdx.x % SEL_COLS_PER_BLOCK, rr = threadIdx.x / SEL_COLS_PER_BLOCK;
         const int cc = min(j0 + c, N - 1);
         double tmp[EPL];
 #pragma unroll
@@ -485,6 +519,10 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
     const int j = j0 + wave;
     if (j >= N) return;
     const int lane = threadIdx.x & 63;
+    if constexpr (MODE == 1) {       // probe: loads only
+        if (colbuf[wave * ldc + lane] == -1.2345) w.col_cut[0] = 0;
+        return;
+    }
     int k = k_mode == 0 ? (int)rint(kappa_k_fixed * (double)M) : (k_mode == 1 ? (int)kappa_k_fixed : M);
     SelectResult res;
     if (trivial_select(k, M, res)) {
@@ -501,8 +539,16 @@ __global__ __launch_bounds__(512) void select_cols_kernel(const double *__restri
             double x[16];
 #pragma unroll
             for (int e = 0; e < 16; e++) x[e] = colbuf[wave * ldc + min(e * 64 + lane, M - 1)] + 0.0;
-            unsigned cold = 0;
-            res = wave_select16(x, ColIdx{lane}, M, k, cold);
+            if constexpr (MODE == 3) {
+                unsigned cold = 0;
+                res = wave_select16(x, ColIdx{lane}, M, k, cold);
+            } else {
+                // the wave's column is in registers now: its LDS slot becomes the histogram
+                unsigned *hist = reinterpret_cast<unsigned *>(colbuf + wave * ldc);
+                hist_clear(hist, lane);
+                HistWarm hw{0, HIST_WARM_SHIFT0};
+                res = wave_select16_hist(x, ColIdx{lane}, M, k, hist, lane, hw);
+            }
             if (w.col_bits && res.cut != SELECT_UNRESOLVED)
                 emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
         } else {
@@ -547,7 +593,7 @@ __global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict
         int idx[16];
 #pragma unroll
         for (int e = 0; e < 16; e++) {
-            idx[e] = DIR == 0 ? RowIdx{lane}(e) : ColIdx{lane}(e);     // the bit words must match the producers'
+            idx[e] = ColIdx{lane}(e);     // the bit words must match the producers'
             const int q = min(idx[e], len - 1);
             const double v = DIR == 0 ? base[(int64_t)which * ds.crp_pitch + q] : base[(int64_t)q * ds.crp_pitch + which];
             key[e] = idx[e] < len ? f64_key(v) : ~0ull;
@@ -604,11 +650,7 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc
     const int i = ri * 64 + lane;
     uint64_t rw = 0;
     if (i < M && cw * 64 < N) {
-        // columns 64cw .. 64cw+63 = half (cw & 1) of the 128-position group cw >> 1: even positions from word
-        // 2q, odd positions from word 2q + 1, 32 bits each, interleaved
-        const uint64_t *rb = w.row_bits + ((int64_t)p * w.max_m + i) * 16 + 2 * (cw >> 1);
-        const int sh = 32 * (cw & 1);
-        rw = spread_bits32((unsigned)(rb[0] >> sh)) | (spread_bits32((unsigned)(rb[1] >> sh)) << 1);
+        rw = w.row_bits[((int64_t)p * w.max_m + i) * 16 + cw];
     }
     if (mutual) {
         const int j = cw * 64 + lane;
@@ -803,8 +845,25 @@ int acoss_dev_select_probe(int mode, const double *S, const acoss_pair_desc *des
     const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
     const unsigned blocks = (unsigned)((int64_t)K * rb);
     hipStream_t st = (hipStream_t)stream;
+    if (mode >= 10) {       // column kernel: 10 = product, 11 = loads only, 13 = sorted / probing selection
+        const int cb = ceil_div(max_n, SEL_COLS_PER_BLOCK);
+        const size_t lds = (size_t)SEL_COLS_PER_BLOCK * (16 * 64 + 2) * sizeof(double);
+        const unsigned cblocks = (unsigned)((int64_t)K * cb);
+        if (mode == 11) {
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((select_cols_kernel<16, 1>), dim3(cblocks), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kappa, 0, w, cb);
+        } else if (mode == 13) {
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((select_cols_kernel<16, 3>), dim3(cblocks), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kappa, 0, w, cb);
+        } else {
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL((select_cols_kernel<16, 0>), dim3(cblocks), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kappa, 0, w, cb);
+        }
+        return launch_check("select_cols probe");
+    }
     if (mode == 1) hipLaunchKernelGGL((select_rows_kernel<16, 1>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
     else if (mode == 2) hipLaunchKernelGGL((select_rows_kernel<16, 2>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
+    else if (mode == 3) hipLaunchKernelGGL((select_rows_kernel<16, 3>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
     else hipLaunchKernelGGL((select_rows_kernel<16, 0>), dim3(blocks), dim3(256), 0, st, S, descs, win, kappa, 0, w, rb);
     return launch_check("select_rows probe");
 }
@@ -883,11 +942,11 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
         if (max_m <= 1024) {
             const size_t lds = sizeof(double) * SEL_COLS_PER_BLOCK * (16 * 64 + 2);
             ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(select_cols_kernel<16>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, S, descs, win, kv, mode, w, cb);
+            hipLaunchKernelGGL(select_cols_kernel<16>, dim3((unsigned)((int64_t)K * cb)), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kv, mode, w, cb);
         } else {
             const size_t lds = sizeof(double) * SEL_COLS_PER_BLOCK * (32 * 64 + 2);
             ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(select_cols_kernel<32>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, S, descs, win, kv, mode, w, cb);
+            hipLaunchKernelGGL(select_cols_kernel<32>, dim3((unsigned)((int64_t)K * cb)), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kv, mode, w, cb);
         }
         int rc = launch_check("select_cols_kernel");
         if (rc) return rc;

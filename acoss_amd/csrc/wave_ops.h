@@ -306,4 +306,161 @@ __device__ inline SelectResult wave_select16(const double (&x)[16], IdxFn idx_of
     return res;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Histogram form of the 16-per-lane selection (the product path).
+//
+// The high words of the keys are binned linearly between the row's minimum and maximum into
+// HIST_BINS wave-private LDS counters (one ds_add per element), a two-level scan of the counters
+// finds the bin that holds the k-th smallest and how many elements lie below it, and only the
+// handful of elements in that bin are ranked against each other by value.  Against the sorted /
+// probing form above this replaces the 63-comparator network and the ~8 counting probes by ~4
+// VALU instructions per element.  Anything unusual (two candidates in one lane, equal candidate
+// values) is left to the fix-up pass, exactly like wave_select16.
+//
+// hist: HIST_WORDS counters private to the wave, zero on entry and zero again on return (the 64
+// trailing words absorb the padding slots and are never read).
+// ---------------------------------------------------------------------------------------------
+constexpr int HIST_BPL = 16;
+constexpr int HIST_BINS = 64 * HIST_BPL;
+constexpr int HIST_LOG2 = 10;
+constexpr int HIST_WORDS = HIST_BINS + 64;
+static_assert((1 << HIST_LOG2) == HIST_BINS, "HIST_LOG2");
+
+__device__ inline void hist_clear(unsigned *hist, int lane)
+{
+#pragma unroll
+    for (int t = 0; t < HIST_BPL / 4; t++)
+        reinterpret_cast<uint4 *>(hist + HIST_BPL * lane)[t] = make_uint4(0, 0, 0, 0);
+    hist[HIST_BINS + lane] = 0;
+}
+
+// Window state carried from one row to the next by the wave that walks them: the high word of the last
+// threshold and the bin width (log2) to use around it.  hi == 0: no prediction, bin the whole range.
+struct HistWarm {
+    unsigned hi;
+    int shift;
+};
+constexpr int HIST_WARM_SHIFT0 = 8, HIST_WARM_SHIFT_MAX = 14;
+
+template <typename IdxFn>
+__device__ inline SelectResult wave_select16_hist(const double (&x)[16], IdxFn idx_of, int n, int k, unsigned *hist,
+                                                  int lane, HistWarm &warm)
+{
+    SelectResult res;
+    res.thr_key = 0;
+    res.cut = SELECT_UNRESOLVED;
+    unsigned bin[16];
+    // pass kinds: a window predicted from the neighbouring row, the full range, or the refinement of one bin
+    // of the previous pass (when two of its elements sit in the same lane)
+    enum { PREDICTED, FULL, REFINE };
+    int kind = warm.hi != 0 ? PREDICTED : FULL;
+    unsigned lo = 0;
+    int shift = warm.shift;
+    if (kind == PREDICTED) {
+        const unsigned half = (unsigned)(HIST_BINS / 2) << shift;
+        lo = max(warm.hi, half) - half;
+    }
+    int r = 0, cstar = 0;
+    double cv = 0.0;
+    uint64_t any = 0;
+    for (;;) {
+        // bins [lo, lo + (HIST_BINS << shift)) of the high words; everything else (and the padding slots)
+        // goes to the lane's spill word; `below` = number of elements under lo
+        int below = 0;
+        if (kind == FULL) {
+            unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const unsigned h = key_hi(x[e]);   // padding slots repeat real elements of the row: harmless here
+                mn = min(mn, h);
+                mx = max(mx, h);
+            }
+            mn = wave_umin(mn);
+            mx = wave_umax(mx);
+            lo = mn;
+            shift = max(0, 32 - (int)__clz(mx - mn) - HIST_LOG2);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++)
+                below += __popcll(__ballot((key_hi(x[e]) < lo) & (idx_of(e) < n)));
+        }
+        const unsigned spill = (unsigned)(HIST_BINS + lane);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            unsigned b = min((key_hi(x[e]) - lo) >> shift, spill);
+            asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
+            bin[e] = idx_of(e) < n ? b : spill;
+            atomicAdd(&hist[bin[e]], 1u);
+        }
+        const int kk = k - below;           // rank among the elements >= lo
+        // level 1: HIST_BPL counters per lane
+        uint4 c4[HIST_BPL / 4];
+        int tot = 0;
+#pragma unroll
+        for (int t = 0; t < HIST_BPL / 4; t++) {
+            c4[t] = reinterpret_cast<const uint4 *>(hist + HIST_BPL * lane)[t];
+            tot += (int)(c4[t].x + c4[t].y + c4[t].z + c4[t].w);
+        }
+        const int incl = wave_scan<OpAdd>(tot, 0);
+        const uint64_t m1 = __ballot((incl - tot < kk) & (kk <= incl));
+        if (m1 == 0) {
+            hist_clear(hist, lane);
+            if (kind != PREDICTED) return res;      // k outside 1..n: cannot happen
+            // the k-th smallest lies outside the predicted window: widen it for the rows to come and bin the
+            // full range now
+            warm.shift = min(warm.shift + 1, HIST_WARM_SHIFT_MAX);
+            kind = FULL;
+            continue;
+        }
+        const int ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
+        const int r0 = kk - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
+        // level 2: the HIST_BPL counters of lane ls, one per lane
+        const int c2 = lane < HIST_BPL ? (int)hist[HIST_BPL * ls + lane] : 0;
+        const int inc2 = wave_scan<OpAdd>(c2, 0);
+        hist_clear(hist, lane);
+        const uint64_t m2 = __ballot((lane < HIST_BPL) & (inc2 >= r0));
+        const int ts = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m2) - 1);
+        cstar = __builtin_amdgcn_readlane(c2, ts);
+        r = r0 - (__builtin_amdgcn_readlane(inc2, ts) - cstar);      // 1-based rank inside the bin
+        const unsigned bstar = (unsigned)(HIST_BPL * ls + ts);
+        // candidates: the elements of bin bstar, one per lane
+        uint64_t dup = 0;
+        any = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const bool in = bin[e] == bstar;
+            const uint64_t m = __ballot(in);
+            dup |= any & m;
+            any |= m;
+            cv = in ? x[e] : cv;
+        }
+        if (dup == 0) break;
+        if (shift == 0) return res;         // same high word in one lane: fix-up pass
+        lo += bstar << shift;
+        shift = max(shift - HIST_LOG2, 0);
+        kind = REFINE;
+    }
+    const bool mine = (any >> lane) & 1;
+    int less = 0, equal = 0;
+    if (cstar > 1) {
+        for (uint64_t rest = any; rest != 0; rest &= rest - 1) {
+            const int c = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)rest) - 1);
+            const double vc = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cv), c),
+                                               __builtin_amdgcn_readlane(__double2loint(cv), c));
+            less += vc < cv;
+            equal += vc == cv;
+        }
+        if (__ballot(mine & (equal > 1)) != 0) return res;      // equal values: position order, fix-up pass
+    }
+    const uint64_t win = __ballot(mine & (less == r - 1));
+    if (win == 0) return res;
+    const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)win) - 1);
+    const double tv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(cv), wl),
+                                       __builtin_amdgcn_readlane(__double2loint(cv), wl));
+    res.thr_key = f64_key(tv);
+    res.cut = 0x7fffffff;
+    warm.hi = key_hi(tv);
+    return res;
+}
+
 }  // namespace acoss

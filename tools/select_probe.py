@@ -17,7 +17,7 @@ work = torch.empty(int(lib.acoss_binarize_work_bytes(K, 1000, 1000, 9)), dtype=t
 fn = lib.acoss_dev_select_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]
-names = {0: "normal", 1: "loads only", 2: "select only"}
+names = {0: "rows", 1: "rows loads only", 2: "rows select only", 3: "rows sorted/probing", 10: "cols", 11: "cols loads only", 13: "cols sorted/probing"}
 res = {m: [] for m in names}
 for rnd in range(5):
     for m in names:
@@ -27,4 +27,21 @@ for rnd in range(5):
         e1.record(); torch.cuda.synchronize()
         if rnd: res[m].append(e0.elapsed_time(e1))
 for m in names:
-    t = np.array(res[m]); print("mode %d %-12s median %.3f ms" % (m, names[m], np.median(t)))
+    t = np.array(res[m]); print("mode %2d %-22s median %.3f ms" % (m, names[m], np.median(t)))
+
+fn(0, engine._ptr(T), engine._ptr(batch.descs_dev), K, 9, 1000, 1000, 0.095, engine._ptr(work), engine._stream())
+torch.cuda.synchronize()
+mm = 992
+off = K * mm * 8 * 2
+cut = work[off:off + K * mm * 4].view(torch.int32).cpu().numpy()
+vals, cnt = np.unique(cut, return_counts=True)
+for v, c in zip(vals, cnt):
+    print("cut %11d (0x%08x): %9d  %.3f%%" % (int(v), int(v) & 0xffffffff, c, 100.0 * c / cut.size))
+
+fn(10, engine._ptr(T), engine._ptr(batch.descs_dev), K, 9, 1000, 1000, 0.095, engine._ptr(work), engine._stream())
+torch.cuda.synchronize()
+off2 = off + K * mm * 4
+cut = work[off2:off2 + K * mm * 4].view(torch.int32).cpu().numpy()
+vals, cnt = np.unique(cut, return_counts=True)
+for v, c in zip(vals, cnt):
+    print("col cut %11d (0x%08x): %9d  %.3f%%" % (int(v), int(v) & 0xffffffff, c, 100.0 * c / cut.size))
