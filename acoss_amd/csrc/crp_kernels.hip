@@ -799,6 +799,15 @@ static void kappa_mode(double kappa, double &kv, int &mode)
     else { kv = kappa; mode = 1; }                   // :192-193
 }
 
+// shared with planar_kernels.hip
+int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st)
+{
+    const int tm = ceil_div(w.max_m, 64), tn = 16;     // all 16 words of every row are written
+    const int64_t waves = (int64_t)K * tm * tn;
+    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, st, descs, K, win, mutual, w, tm, tn, bits);
+    return launch_check("combine_bits_kernel");
+}
+
 }  // namespace acoss
 
 using namespace acoss;
@@ -981,10 +990,7 @@ int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, 
     ThreshWork w;
     int rc = run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, st, w, true);
     if (rc || K == 0) return rc;
-    const int tm = ceil_div(w.max_m, 64), tn = 16;     // all 16 words of every row are written
-    const int64_t waves = (int64_t)K * tm * tn;
-    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, st, descs, K, win, mutual, w, tm, tn, bits);
-    return launch_check("combine_bits_kernel");
+    return launch_combine_bits(descs, K, win, mutual, w, bits, st);
 }
 
 int acoss_binarize_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,

@@ -376,7 +376,13 @@ constexpr int STRIP_ROWS = 32;
 // 3 = no MFMA phase (stale LDS contents summed)
 // CSM_LAYOUT: write at the pair's csm_off / csm_pitch instead of crp_off / crp_pitch (WIN = 1 with
 // SQRT_OUT is then exactly get_csm, CRPUtils.py:67-84).
-template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false>
+// PLANAR ("split-line" layout): the result occupies the bytes of the float64 matrix, but every aligned block of
+// 32 values (256 bytes) is stored as the 32 high words followed by the 32 low words of the values'
+// order-preserving keys (wave_ops.h:f64_key; the sums are >= +0.0, so that is the bit pattern with the sign
+// bit set): value number idx of the float64 layout has its high word at word 64 * (idx / 32) + idx % 32 and its
+// low word 32 words later.  The selection kernels then read only the high-word half of every block -- whole
+// 128-byte lines, 4 bytes per element -- while this kernel writes the same contiguous byte ranges as before.
+template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false, bool PLANAR = false>
 __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
                                                         const double *__restrict__ feats, const double *__restrict__ norms,
                                                         const acoss_pair_desc *__restrict__ descs, int strips,
@@ -450,6 +456,10 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     const int64_t o_off = CSM_LAYOUT ? ds.csm_off : ds.crp_off;
     const int o_pitch = CSM_LAYOUT ? ds.csm_pitch : ds.crp_pitch;
     double *orow = out + o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;
+    const bool quad_ok = ((o_pitch & 3) == 0) && ((o_off & 3) == 0) && (TN % 4 == 0);   // block-uniform
+    const int64_t pidx0 = o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;   // float64 index of (first row of the wave, strip column 0)
+    uint32_t *const pwords = reinterpret_cast<uint32_t *>(out);
+    static_assert(!PLANAR || ((TN + ROWS_PER_WAVE <= CRP_CT) && !SQRT_OUT && !CSM_LAYOUT), "planar output: diagonal-run form only");
 
     // x frames are fetched two steps ahead (registers), so their HBM latency spans a whole step
     double2 xn1 = make_double2(0.0, 0.0), xn2 = make_double2(0.0, 0.0);
@@ -525,19 +535,72 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                 }
                 double *o = orow + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
                 const int col = dcol + q;
-                if (MODE == 1) {
+                if constexpr (PLANAR) {
+                    // high-word address of strip column c of this row (low word: + 32)
+                    // (wave-uniform block base + a 32-bit lane offset: idx = 32 A + u  ->  word 64 A + u + (u & ~31))
+                    const int64_t pidx = pidx0 + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
+                    uint32_t *const rowbase = pwords + ((pidx >> 5) << 6);
+                    const int pb = (int)(pidx & 31);
+                    auto hw = [&](const int c) { const unsigned u = (unsigned)max(pb + c, 0); return rowbase + (u + (u & ~31u)); };   // c < 0: masked lanes
+                    const uint32_t ha = (uint32_t)__double2hiint(sa) | 0x80000000u, la = (uint32_t)__double2loint(sa);
+                    const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u, lb = (uint32_t)__double2loint(sb);
+                    if (CHECKED) {
+                        const bool row_ok = gi >= 0 && gi < M;
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) { uint32_t *a = hw(col); a[0] = ha; a[32] = la; }
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) { uint32_t *a = hw(col + 1); a[0] = hb; a[32] = lb; }
+                    } else {
+                        // this lane's pair of the row: columns ps, ps + 1 (ps even)
+                        uint32_t h0 = ha, h1 = hb, l0 = la, l1 = lb;
+                        int ps = col;
+                        if ((q & 1) != 0) {
+                            h0 = hb; l0 = lb;
+                            h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x130, 0xf, 0xf, true);   // wave_shl:1
+                            l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)la, 0x130, 0xf, 0xf, true);
+                            ps = col + 1;
+                        }
+                        if (quad_ok) {
+                            // two neighbouring lanes hold four adjacent columns: the one whose pair starts the
+                            // aligned quad writes the four high words (16 bytes to plane 0), the other one the
+                            // four low words (plane 1) -- one 16-byte store per lane and row, as in the float64 form
+                            const int EQ = (q & 1) ? q - (ROWS_PER_WAVE - 1) : q - ROWS_PER_WAVE;      // ps = 2 * lane + EQ (constant after unrolling)
+                            uint32_t g0, g1;
+                            bool leader;
+                            if ((EQ & 3) == 0) {
+                                leader = (lane & 1) == 0;
+                                g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l0 : h0), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
+                                g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l1 : h1), 0xB1, 0xf, 0xf, true);
+                            } else {
+                                leader = (lane & 1) != 0;
+                                const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x130, 0xf, 0xf, true);      // from lane + 1
+                                const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0x130, 0xf, 0xf, true);
+                                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l0, 0x138, 0xf, 0xf, true);      // from lane - 1
+                                const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l1, 0x138, 0xf, 0xf, true);
+                                g0 = leader ? a0 : b0;
+                                g1 = leader ? a1 : b1;
+                            }
+                            const int qs = leader ? ps : ps - 2;
+                            const uint4 v = leader ? make_uint4(h0, h1, g0, g1) : make_uint4(g0, g1, l0, l1);
+                            if (qs >= 0 && qs < TN) *reinterpret_cast<uint4 *>(hw(qs) + (leader ? 0 : 32)) = v;
+                        } else if (ps >= 0 && ps < TN) {
+                            uint32_t *a = hw(ps);
+                            *reinterpret_cast<uint2 *>(a) = make_uint2(h0, h1);
+                            *reinterpret_cast<uint2 *>(a + 32) = make_uint2(l0, l1);
+                        }
+                    }
+                } else if (MODE == 1) {
                     if (sa == -1.25) o[col & 63] = sb;
                 } else if (CHECKED) {
                     const bool row_ok = gi >= 0 && gi < M;
-                    if (row_ok && col >= 0 && col < TN && j0 + col < N) o[col] = sa;
-                    if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) o[col + 1] = sb;
+                    if (row_ok && col >= 0 && col < TN && j0 + col < N) o[(unsigned)max(col, 0)] = sa;
+                    if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) o[(unsigned)max(col + 1, 0)] = sb;
                 } else if ((q & 1) == 0) {
-                    if (col >= 0 && col < TN) *reinterpret_cast<double2 *>(o + col) = make_double2(sa, sb);
+                    // (unsigned lane offsets from the wave-uniform row pointer: no 64-bit address registers)
+                    if (col >= 0 && col < TN) *reinterpret_cast<double2 *>(o + (unsigned)max(col, 0)) = make_double2(sa, sb);
                 } else {
                     const int glo = __builtin_amdgcn_update_dpp(0, __double2loint(sa), 0x130, 0xf, 0xf, true);   // wave_shl:1
                     const int ghi = __builtin_amdgcn_update_dpp(0, __double2hiint(sa), 0x130, 0xf, 0xf, true);
                     if (col + 1 >= 0 && col + 1 < TN)
-                        *reinterpret_cast<double2 *>(o + col + 1) = make_double2(sb, __hiloint2double(ghi, glo));
+                        *reinterpret_cast<double2 *>(o + (unsigned)max(col + 1, 0)) = make_double2(sb, __hiloint2double(ghi, glo));
                 }
             }
         } else {
@@ -641,6 +704,16 @@ static void launch_crp_strip(const double *xp, int max_nx, const double *feats, 
     const unsigned blocks = (unsigned)((int64_t)K * strips);
     if (sqrt_out) hipLaunchKernelGGL((crp_strip_kernel<D, WIN, true>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else hipLaunchKernelGGL((crp_strip_kernel<D, WIN, false>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+}
+
+template <int D>
+static void launch_crp_strip_planar(const double *xp, int max_nx, const double *feats, const double *norms,
+                                    const acoss_pair_desc *descs, int K, int max_ny, uint32_t *planes, hipStream_t st)
+{
+    const int strips = ceil_div(max_ny - 9 + 1, CRP_CT - 8);
+    const unsigned blocks = (unsigned)((int64_t)K * strips);
+    hipLaunchKernelGGL((crp_strip_kernel<D, 9, false, 0, false, true>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms,
+                       descs, strips, reinterpret_cast<double *>(planes));
 }
 
 template <int D>
@@ -781,6 +854,24 @@ int acoss_crp_batch_f64(const double *xp, const double *feats, const double *nor
                         double *out, void *stream)
 {
     return launch_crp<double>(xp, feats, norms, d, descs, K, win, max_nx, max_ny, sqrt_out, out, (hipStream_t)stream);
+}
+int acoss_crp_planar_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                               const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                               uint32_t *planes, void *stream)
+{
+    if (!xp || !feats || !norms || !descs || !planes || K < 0 || max_nx < win || max_ny < win) {
+        set_error("crp_planar_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if ((d != 12 && d != 13) || win != 9) {
+        set_error("crp_planar_batch: supports d in {12, 13} and win == 9 (use crp_batch otherwise)");
+        return ACOSS_ENOTSUP;
+    }
+    if (K == 0) return ACOSS_OK;
+    if ((int64_t)K * ceil_div(max_ny - win + 1, CRP_CT - (win - 1)) > 0x7fffffffLL) { set_error("crp_planar_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if (d == 12) launch_crp_strip_planar<12>(xp, max_nx, feats, norms, descs, K, max_ny, planes, (hipStream_t)stream);
+    else launch_crp_strip_planar<13>(xp, max_nx, feats, norms, descs, K, max_ny, planes, (hipStream_t)stream);
+    return launch_check("crp_strip_kernel<planar>");
 }
 int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms, int d,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,

@@ -1,0 +1,472 @@
+// planar_kernels.hip -- kNN selection (CRPUtils.py:169-219) on the split-line form of the windowed sums
+// written by crp_strip_kernel<..., PLANAR>: every aligned block of 32 values of the float64 layout is stored as
+// 32 high words + 32 low words of the values' order-preserving keys (value idx: high word at word
+// 64 * (idx / 32) + idx % 32, low word 32 words later).
+//
+// Why: the selection kernels of crp_kernels.hip run at 75 % of their load-only time -- they are bound by
+// reading 8 bytes per element of T, twice (rows, columns).  The k-th smallest of a row is decided by the high
+// words alone unless another element shares the winner's high word (~6e-4 of the rows at 992 columns); those
+// rows and columns go to the fix-up kernel, which reads both words.  So the two big kernels read 4 bytes per
+// element (whole 128-byte lines), hold 16 instead of 32 registers of data per lane, and need no key
+// conversion.
+//
+// Outputs are the same as acoss_mask_bits_batch: thresholds (key = high word : 0xffffffff, which selects
+// exactly the same elements as the full key of the k-th smallest when its high word is unique), tie cuts,
+// and the row / column bit planes that combine_bits_kernel turns into the bit-packed mutual mask.
+#include "common.h"
+#include "kernel_utils.h"
+#include "thresh_work.h"
+#include "wave_ops.h"
+
+namespace acoss {
+
+// ---- shared with crp_kernels.hip (same definitions; both are internal) -------------------------------------
+__device__ inline void planar_put_lane_u64(unsigned &lo, unsigned &hi, uint64_t m, int e)
+{
+    // s_nop: VALU-writes-SGPR -> VALU-reads-SGPR wait states the hazard recogniser does not insert around asm
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4"
+        : "+v"(lo), "+v"(hi)
+        : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(e));
+}
+
+// lane e (< 16) = lane mask of "position e*64 + lane exists"
+__device__ inline uint64_t planar_slot_valid(int n, int lane)
+{
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) planar_put_lane_u64(lo, hi, __ballot(e * 64 + lane < n), e);
+    return ((uint64_t)hi << 32) | lo;
+}
+
+// word e of out = lanes whose element e is selected (high word <= the threshold's), positions e*64 + lane
+__device__ inline void planar_emit_bits(const unsigned (&h)[16], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane)
+{
+    unsigned lo = 0, hi = 0;
+#pragma unroll
+    for (int e = 0; e < 16; e++) planar_put_lane_u64(lo, hi, __ballot(h[e] <= thr_hi), e);
+    if (lane < 16) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
+}
+
+// k-th smallest of the n high words a wave holds (h[e] = position e*64 + lane; positions >= n repeat a real
+// element and are ignored), by the histogram method of wave_select16_hist (wave_ops.h).  Returns the winning
+// high word with cut = INT_MAX when no other element shares it, else cut = SELECT_UNRESOLVED.
+__device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], int n, int k, unsigned *hist, int lane,
+                                                      HistWarm &warm)
+{
+    SelectResult res;
+    res.thr_key = 0;
+    res.cut = SELECT_UNRESOLVED;
+    unsigned bin[16];
+    enum { PREDICTED, FULL, REFINE };
+    int kind = warm.hi != 0 ? PREDICTED : FULL;
+    unsigned lo = 0;
+    int shift = warm.shift;
+    if (kind == PREDICTED) {
+        const unsigned half = (unsigned)(HIST_BINS / 2) << shift;
+        lo = max(warm.hi, half) - half;
+    }
+    int r = 0, cstar = 0;
+    unsigned ch = 0;
+    uint64_t any = 0;
+    for (;;) {
+        int below = 0;
+        if (kind == FULL) {
+            unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                mn = min(mn, h[e]);
+                mx = max(mx, h[e]);
+            }
+            mn = wave_umin(mn);
+            mx = wave_umax(mx);
+            lo = mn;
+            shift = max(0, 32 - (int)__clz(mx - mn) - HIST_LOG2);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) below += __popcll(__ballot((h[e] < lo) & (e * 64 + lane < n)));
+        }
+        const unsigned spill = (unsigned)(HIST_BINS + lane);
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            unsigned b = min((h[e] - lo) >> shift, spill);
+            asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
+            bin[e] = e * 64 + lane < n ? b : spill;
+            atomicAdd(&hist[bin[e]], 1u);
+        }
+        const int kk = k - below;
+        uint4 c4[HIST_BPL / 4];
+        int tot = 0;
+#pragma unroll
+        for (int t = 0; t < HIST_BPL / 4; t++) {
+            c4[t] = reinterpret_cast<const uint4 *>(hist + HIST_BPL * lane)[t];
+            tot += (int)(c4[t].x + c4[t].y + c4[t].z + c4[t].w);
+        }
+        const int incl = wave_scan<OpAdd>(tot, 0);
+        const uint64_t m1 = __ballot((incl - tot < kk) & (kk <= incl));
+        if (m1 == 0) {
+            hist_clear(hist, lane);
+            if (kind != PREDICTED) return res;
+            warm.shift = min(warm.shift + 1, HIST_WARM_SHIFT_MAX);
+            kind = FULL;
+            continue;
+        }
+        const int ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
+        const int r0 = kk - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
+        const int c2 = lane < HIST_BPL ? (int)hist[HIST_BPL * ls + lane] : 0;
+        const int inc2 = wave_scan<OpAdd>(c2, 0);
+        hist_clear(hist, lane);
+        const uint64_t m2 = __ballot((lane < HIST_BPL) & (inc2 >= r0));
+        const int ts = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m2) - 1);
+        cstar = __builtin_amdgcn_readlane(c2, ts);
+        r = r0 - (__builtin_amdgcn_readlane(inc2, ts) - cstar);
+        const unsigned bstar = (unsigned)(HIST_BPL * ls + ts);
+        uint64_t dup = 0;
+        any = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            const bool in = bin[e] == bstar;
+            const uint64_t m = __ballot(in);
+            dup |= any & m;
+            any |= m;
+            ch = in ? h[e] : ch;
+        }
+        if (dup == 0) break;
+        if (shift == 0) return res;         // equal high words: both planes needed, fix-up pass
+        lo += bstar << shift;
+        shift = max(shift - HIST_LOG2, 0);
+        kind = REFINE;
+    }
+    const bool mine = (any >> lane) & 1;
+    int less = 0, equal = 1;
+    if (cstar > 1) {
+        equal = 0;
+        for (uint64_t rest = any; rest != 0; rest &= rest - 1) {
+            const int c = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)rest) - 1);
+            const unsigned vc = (unsigned)__builtin_amdgcn_readlane((int)ch, c);
+            less += vc < ch;
+            equal += vc == ch;
+        }
+    }
+    // the winner: `less` smaller candidates, and with ties less < r <= less + equal
+    const uint64_t win = __ballot(mine & (less < r) & (r <= less + equal));
+    if (win == 0) return res;
+    const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)win) - 1);
+    if (__builtin_amdgcn_readlane(equal, wl) > 1) return res;       // shared high word: low words decide
+    const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)ch, wl);
+    res.thr_key = ((uint64_t)th << 32) | 0xffffffffull;
+    res.cut = 0x7fffffff;
+    warm.hi = th;
+    return res;
+}
+
+// word index of the high word of float64 element idx (low word: + 32)
+__device__ inline int64_t planar_word(int64_t idx) { return ((idx >> 5) << 6) + (idx & 31); }
+
+__device__ inline bool planar_trivial(int k, int n, SelectResult &r)
+{
+    if (k <= 0) { r.thr_key = 0ull; r.cut = -1; return true; }
+    if (k >= n) { r.thr_key = ~0ull; r.cut = 0x7fffffff; return true; }
+    return false;
+}
+
+__device__ inline int knn_count(int k_mode, double kv, int len)
+{
+    // CRPUtils.py:190-193; half-even rounding (np.round) = rint under the default rounding mode
+    return k_mode == 0 ? (int)rint(kv * (double)len) : (k_mode == 1 ? (int)kv : len);
+}
+
+// ---- rows ------------------------------------------------------------------------------------------------
+constexpr int PL_ROWS_PER_WAVE = 8;
+
+// MODE (development probes): 1 = loads only
+template <int MODE = 0>
+__global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32_t *__restrict__ Thi,
+                                                                   const acoss_pair_desc *__restrict__ descs, int win,
+                                                                   double kv, int k_mode, ThreshWork w, int rows_blocks)
+{
+    __shared__ __attribute__((aligned(16))) unsigned hist_all[4 * HIST_WORDS];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / rows_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = ((lb % rows_blocks) * 4 + wave) * PL_ROWS_PER_WAVE;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (r0 >= M) return;
+    const int r1 = min(r0 + PL_ROWS_PER_WAVE, M);
+    const int lane = threadIdx.x & 63;
+    const int k = knn_count(k_mode, kv, N);
+    uint64_t *thr = w.row_thr + (int64_t)p * w.max_m;
+    int *cut = w.row_cut + (int64_t)p * w.max_m;
+    unsigned *hist = hist_all + wave * HIST_WORDS;
+    hist_clear(hist, lane);
+    HistWarm warm{0, HIST_WARM_SHIFT0};
+    const uint64_t valid = planar_slot_valid(N, lane);
+    const bool wide = N > 15 * 64;       // wave-uniform: only the last slot can run past the row
+    // rows that start a 32-value block (pitch and offset multiples of 32): element e*64 + lane is word
+    // 128 e + lane + 32 (lane / 32) of the row -- two whole high-word lines per load instruction
+    const bool aligned = ((ds.crp_off & 31) == 0) && ((ds.crp_pitch & 31) == 0);
+    const unsigned lane_w = (unsigned)(lane + 32 * (lane >> 5));
+    for (int i = r0; i < r1; i++) {
+        const int64_t idx0 = ds.crp_off + (int64_t)i * ds.crp_pitch;
+        unsigned h[16];
+        if (aligned) {
+            const uint32_t *row = Thi + 2 * idx0;
+            if (wide) {
+#pragma unroll
+                for (int e = 0; e < 15; e++) h[e] = row[(unsigned)(128 * e) + lane_w];
+                const int pl = min(15 * 64 + lane, N - 1);
+                h[15] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 16; e++) {
+                    const int pl = min(e * 64 + lane, N - 1);
+                    h[e] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e++) h[e] = Thi[planar_word(idx0 + min(e * 64 + lane, N - 1))];
+        }
+        if constexpr (MODE == 1) {
+            unsigned acc = 0;
+#pragma unroll
+            for (int e = 0; e < 16; e++) acc += h[e];
+            if (acc == 0x12345u) thr[i] = 0;
+            continue;
+        }
+        SelectResult res;
+        if (!planar_trivial(k, N, res)) res = wave_select16_hist_u32(h, N, k, hist, lane, warm);
+        if (lane == 0) {
+            thr[i] = res.thr_key;
+            cut[i] = res.cut;
+        }
+        if (w.row_bits && res.cut != SELECT_UNRESOLVED)
+            planar_emit_bits(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
+                             w.row_bits + ((int64_t)p * w.max_m + i) * 16, lane);
+    }
+}
+
+// ---- columns ---------------------------------------------------------------------------------------------
+// One 8-wave block stages 16 columns (64-byte row segments, 16-byte loads) through LDS; wave v then selects
+// in columns 2v and 2v + 1, the second one inside the window predicted by the first.  Once a wave holds its
+// two columns in registers their LDS slots become its histogram.
+constexpr int PL_COLS = 16;
+constexpr int PL_LDC = 1024 + 4;        // words per staged column
+
+template <int MODE = 0>
+__global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32_t *__restrict__ Thi,
+                                                                   const acoss_pair_desc *__restrict__ descs, int win,
+                                                                   double kv, int k_mode, ThreshWork w, int col_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned pcolbuf[];      // [PL_COLS][PL_LDC]
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / col_blocks;
+    const int j0 = (lb % col_blocks) * PL_COLS;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (j0 >= N) return;
+    {
+        // 64 rows x 8 column pairs per sweep (8-byte loads, 64-byte row segments), 16 sweeps (M <= 1024).
+        // (16-byte loads with 4 lanes per row segment take 2.3x as long: measured.)
+        const int c2 = threadIdx.x & 7, rr = threadIdx.x >> 3;
+        const bool vec_ok = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0) && (j0 + PL_COLS <= N);   // block-uniform
+        uint2 tmp[16];
+        if (vec_ok) {
+#pragma unroll
+            for (int s = 0; s < 16; s++)
+                tmp[s] = *reinterpret_cast<const uint2 *>(Thi + planar_word(ds.crp_off + (int64_t)min(s * 64 + rr, M - 1) * ds.crp_pitch + j0 + 2 * c2));
+        } else {
+#pragma unroll
+            for (int s = 0; s < 16; s++) {
+                const int64_t ri = ds.crp_off + (int64_t)min(s * 64 + rr, M - 1) * ds.crp_pitch;
+                tmp[s].x = Thi[planar_word(ri + min(j0 + 2 * c2 + 0, N - 1))];
+                tmp[s].y = Thi[planar_word(ri + min(j0 + 2 * c2 + 1, N - 1))];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            unsigned *dst = pcolbuf + (2 * c2) * PL_LDC + s * 64 + rr;
+            dst[0 * PL_LDC] = tmp[s].x;
+            dst[1 * PL_LDC] = tmp[s].y;
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int ja = j0 + 2 * wave;
+    if (ja >= N) return;
+    if constexpr (MODE == 1) {
+        if (pcolbuf[(2 * wave) * PL_LDC + lane] == 0x12345u) w.col_cut[0] = 0;
+        return;
+    }
+    unsigned ha[16], hb[16];
+#pragma unroll
+    for (int e = 0; e < 16; e++) {
+        const int row = min(e * 64 + lane, M - 1);
+        ha[e] = pcolbuf[(2 * wave) * PL_LDC + row];
+        hb[e] = pcolbuf[(2 * wave + 1) * PL_LDC + row];
+    }
+    unsigned *hist = pcolbuf + (2 * wave) * PL_LDC;      // 2 * PL_LDC words >= HIST_WORDS, 16-byte aligned
+    hist_clear(hist, lane);
+    const int k = knn_count(k_mode, kv, M);
+    const uint64_t valid = planar_slot_valid(M, lane);
+    HistWarm warm{0, HIST_WARM_SHIFT0};
+    auto column = [&](const unsigned (&h)[16], const int j) {
+        SelectResult res;
+        if (!planar_trivial(k, M, res)) res = wave_select16_hist_u32(h, M, k, hist, lane, warm);
+        if (lane == 0) {
+            w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
+            w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
+        }
+        if (w.col_bits && res.cut != SELECT_UNRESOLVED)
+            planar_emit_bits(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
+                             w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+    };
+    column(ha, ja);
+    if (ja + 1 < N) column(hb, ja + 1);
+}
+
+// ---- fix-up: rows / columns whose winner shares its high word -----------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi,
+                                                               const acoss_pair_desc *__restrict__ descs, int win,
+                                                               double kv, int k_mode, ThreshWork w, int groups)
+{
+    const int p = blockIdx.x / groups, g = blockIdx.x % groups;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int count = DIR == 0 ? M : N;
+    const int len = DIR == 0 ? N : M;
+    const int lane = threadIdx.x;
+    const int t = g * 64 + lane;
+    uint64_t *thr = (DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n);
+    int *cut = (DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n);
+    unsigned long long todo = __ballot(t < count && cut[t] == SELECT_UNRESOLVED);
+    if (todo == 0) return;
+    const int k = knn_count(k_mode, kv, len);
+    while (todo) {
+        const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
+        todo &= todo - 1;
+        uint64_t key[16];
+        int idx[16];
+#pragma unroll
+        for (int e = 0; e < 16; e++) {
+            idx[e] = e * 64 + lane;
+            const int q = min(idx[e], len - 1);
+            const int64_t at = planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which));
+            key[e] = idx[e] < len ? (((uint64_t)Thi[at] << 32) | Thi[at + 32]) : ~0ull;
+        }
+        const SelectResult res = wave_select_kth<16>(key, idx, len, k);
+        if (lane == 0) {
+            thr[which] = res.thr_key;
+            cut[which] = res.cut;
+        }
+        uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
+        if (bits) {
+            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * 16;
+            uint64_t mine = 0;
+#pragma unroll
+            for (int e = 0; e < 16; e++) {
+                const bool on = (idx[e] < len) & ((key[e] < res.thr_key) | ((key[e] == res.thr_key) & (idx[e] <= res.cut)));
+                const uint64_t m = __ballot(on);
+                if (lane == e) mine = m;
+            }
+            if (lane < 16) bits[lane] = mine;
+        }
+    }
+}
+
+// defined in crp_kernels.hip
+int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st);
+
+static void kappa_mode_planar(double kappa, double &kv, int &mode)
+{
+    if (kappa == 0.0) { kv = 0.0; mode = 2; }       // CRPUtils.py:188-189
+    else if (kappa < 1.0) { kv = kappa; mode = 0; }  // :190-191
+    else { kv = kappa; mode = 1; }                   // :192-193
+}
+
+static int run_planar(int probe, const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+                      int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes,
+                      hipStream_t st)
+{
+    if (!planes || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
+        set_error("mask_bits_planar: bad argument");
+        return ACOSS_EINVAL;
+    }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    if (max_m > 1024 || max_n > 1024) {
+        set_error("mask_bits_planar: matrices larger than 1024 x 1024 are not supported");
+        return ACOSS_ENOTSUP;
+    }
+    if (work_bytes < thresh_work_bytes(K, max_m, max_n, true)) {
+        set_error("mask_bits_planar: workspace too small");
+        return ACOSS_EINVAL;
+    }
+    ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    if (K == 0) return ACOSS_OK;
+    double kv;
+    int mode;
+    kappa_mode_planar(kappa, kv, mode);
+    const int rb = ceil_div(max_m, 4 * PL_ROWS_PER_WAVE);
+    const int cb = ceil_div(max_n, PL_COLS);
+    const size_t lds = sizeof(unsigned) * PL_COLS * PL_LDC;
+    if ((int64_t)K * rb > 0x7fffffffLL || (int64_t)K * cb > 0x7fffffffLL) { set_error("mask_bits_planar: batch too large"); return ACOSS_ENOTSUP; }
+    if (probe == 1) {
+        hipLaunchKernelGGL(select_rows_planar_kernel<1>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
+        return launch_check("select_rows_planar probe");
+    }
+    if (probe == 11) {
+        ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(select_cols_planar_kernel<1>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, planes, descs, win, kv, mode, w, cb);
+        return launch_check("select_cols_planar probe");
+    }
+    if (probe == 0 || probe == 2) {
+        hipLaunchKernelGGL(select_rows_planar_kernel<0>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
+        int rc = launch_check("select_rows_planar_kernel");
+        if (rc) return rc;
+        if (probe == 2) return ACOSS_OK;
+        const int groups = ceil_div(max_m, 64);
+        hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, descs, win, kv, mode, w, groups);
+        rc = launch_check("select_fix_planar_kernel<rows>");
+        if (rc) return rc;
+    }
+    if (mutual || probe == 12) {
+        ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(select_cols_planar_kernel<0>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, planes, descs, win, kv, mode, w, cb);
+        int rc = launch_check("select_cols_planar_kernel");
+        if (rc) return rc;
+        if (probe == 12) return ACOSS_OK;
+        const int groups = ceil_div(max_n, 64);
+        hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, descs, win, kv, mode, w, groups);
+        rc = launch_check("select_fix_planar_kernel<cols>");
+        if (rc) return rc;
+    }
+    return launch_combine_bits(descs, K, win, mutual, w, bits, st);
+}
+
+}  // namespace acoss
+
+using namespace acoss;
+
+extern "C" {
+
+int acoss_mask_bits_planar_batch(const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+                                 int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
+                                 size_t work_bytes, void *stream)
+{
+    if (!bits) { set_error("mask_bits_planar_batch: bad argument"); return ACOSS_EINVAL; }
+    return run_planar(0, planes, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, work_bytes,
+                      (hipStream_t)stream);
+}
+
+// development probe (not part of the public ABI): 1 = row loads only, 2 = row selection kernel alone,
+// 11 = column loads only, 12 = column selection kernel alone
+int acoss_dev_planar_probe(int probe, const uint32_t *planes, const acoss_pair_desc *descs, int K,
+                           int win, int max_nx, int max_ny, double kappa, void *work, size_t work_bytes, void *stream)
+{
+    return run_planar(probe, planes, descs, K, win, max_nx, max_ny, kappa, 1, nullptr, work, work_bytes,
+                      (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -196,6 +196,32 @@ def crp(corpus, batch, xp, sqrt_out=False, out=None, force_valu=False, force_til
     return out
 
 
+def crp_planar(corpus, batch, xp, out=None):
+    """The windowed sums of crp() in the split-line layout (every aligned block of 32 values = 32 high words +
+    32 low words of the order-preserving keys; include/acoss_mi355x.h) -- the input of mask_bits_planar().
+    int32 tensor of 2 * planar_elems(batch) words.  float64 features, win == 9, d in {12, 13}."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(2 * planar_elems(batch), dtype=torch.int32, device=corpus.device)
+    check(lib.acoss_crp_planar_batch_f64(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                         _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny,
+                                         _ptr(out), _stream()), "crp_planar_batch")
+    return out
+
+
+def planar_elems(batch):
+    """float64 extent of the batch rounded up to whole 32-value blocks."""
+    return (max(batch.total_crp, 1) + 31) & ~31
+
+
+PLANAR_PITCH_ALIGN = 32     # PairBatch(pitch_align=...) that puts every row on a block boundary
+
+
+def planar_supported(corpus, batch):
+    return (corpus.dtype == np.float64 and corpus.d in (12, 13) and batch.win == 9
+            and bits_path_supported(batch))
+
+
 def crp_supported(corpus, win):
     return corpus.d in (12, 13) and 1 <= win <= 16
 
@@ -261,6 +287,21 @@ def mask_bits(S_buf, batch, kappa, mutual=True, out=None, work=None):
     check(lib.acoss_mask_bits_batch(_ptr(S_buf), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
                                     batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out), _ptr(work),
                                     work.numel(), _stream()), "mask_bits_batch")
+    return out, work
+
+
+def mask_bits_planar(planes, batch, kappa, mutual=True, out=None, work=None):
+    """mask_bits() from the two-plane form of crp_planar(): identical result, half the bytes read."""
+    lib = _lib.load()
+    max_m = batch.max_nx - batch.win + 1
+    if out is None:
+        out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=planes.device)
+    need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=planes.device)
+    check(lib.acoss_mask_bits_planar_batch(_ptr(planes), _ptr(batch.descs_dev), batch.K, batch.win,
+                                           batch.max_nx, batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out),
+                                           _ptr(work), work.numel(), _stream()), "mask_bits_planar_batch")
     return out, work
 
 
@@ -342,17 +383,23 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     xp = T = B = work = None
     for lo in range(0, K, batch_pairs):
         sel = pairs[lo:lo + batch_pairs]
-        batch = PairBatch(corpus.frame_off, sel, m, corpus.device)
+        batch = PairBatch(corpus.frame_off, sel, m, corpus.device, pitch_align=PLANAR_PITCH_ALIGN)
         if do_oti:
             oti(corpus, batch)
         xp = pack_x(corpus, batch, out=xp)
-        if T is None or T.numel() < batch.total_crp:
-            T = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
+        if T is None or T.numel() < planar_elems(batch):
+            T = torch.empty(planar_elems(batch), dtype=torch.float64, device=corpus.device)
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
-        crp(corpus, batch, xp, sqrt_out=False, out=T)
         denom = (batch.M + batch.N).astype(np.float64)
-        if bits_path_supported(batch):
-            bits, work = mask_bits(T, batch, kappa, mutual=True, work=work)
+        if planar_supported(corpus, batch):
+            # same bytes as T, viewed as the two uint32 planes
+            planes = crp_planar(corpus, batch, xp, out=T[:planar_elems(batch)].view(torch.int32))
+            bits, work = mask_bits_planar(planes, batch, kappa, mutual=True, work=work)
+        else:
+            crp(corpus, batch, xp, sqrt_out=False, out=T)
+        if planar_supported(corpus, batch) or bits_path_supported(batch):
+            if not planar_supported(corpus, batch):
+                bits, work = mask_bits(T, batch, kappa, mutual=True, work=work)
             if "qmax" in want:
                 out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
             if "dmax" in want:

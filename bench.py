@@ -44,8 +44,10 @@ def parse():
     ap.add_argument("--pairs-per-step", type=int, default=2048)
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--path", choices=("fast", "staged"), default="fast",
-                    help="fast: fused CSM+sliding kernel (the product path); staged: one kernel per reference function")
+    ap.add_argument("--path", choices=("fast", "fast_f64", "staged"), default="fast",
+                    help="fast: fused CSM+sliding kernel writing two uint32 planes, selection on the high words (the "
+                         "product path); fast_f64: the same with a float64 matrix in between; staged: one kernel per "
+                         "reference function")
     ap.add_argument("--overlap", action="store_true",
                     help="fast path: run the alignment sweep of batch b on a second HIP stream while the main "
                          "stream computes batch b+1 (measured: no gain, the sweep's registers/LDS crowd the CUs)")
@@ -55,6 +57,7 @@ def parse():
 
 
 STAGES = {"fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
+          "fast_f64": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
 
 
@@ -73,12 +76,17 @@ class Runner(object):
         # fast path: the alignment sweep (latency-bound: 992 serial row steps, ~15 % VALU) of batch b runs
         # on a second HIP stream while the main stream already computes batch b+1 (two sets of T/threshold
         # buffers, events both ways)
-        self.overlap = overlap and path == "fast"
+        self.overlap = overlap and path == "fast_f64"
+        # "fast": T leaves the strip kernel as two uint32 planes (key high / low words) and the selections read
+        # only the high-word plane; "fast_f64": T as float64, selections read 8 bytes per element
+        self.planar = path == "fast" and all(engine.planar_supported(corpus, b) for b in batches)
+        if path == "fast_f64":
+            path = self.path = "fast"
         self.corpus, self.m, self.kappa = corpus, m, kappa
         dev = corpus.device
         lib = engine._lib.load()
         tr = max(b.total_crp for b in batches)
-        self.S = torch.empty(tr, dtype=torch.float64, device=dev)
+        self.S = torch.empty(tr + 32, dtype=torch.float64, device=dev)
         self.B = torch.zeros(tr, dtype=torch.uint8, device=dev) if path == "staged" else None
         if path == "staged":
             self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
@@ -143,14 +151,21 @@ class Runner(object):
         if self.path == "fast":
             e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)
+            if self.planar:
+                planes = self.S[:e.planar_elems(b)].view(self.torch.int32)
+                e.crp_planar(self.corpus, b, self.xp, out=planes)
+            else:
+                e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)
         else:
             e.csm(self.corpus, b, out=self.C)
             mark(2)
             e.sliding(self.C, b, out=self.S)
         mark(3)
         if self.path == "fast":
-            e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
+            if self.planar:
+                e.mask_bits_planar(planes, b, self.kappa, True, out=self.bits, work=self.work)
+            else:
+                e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
             mark(4)
             e.align_bits("qmax", self.bits, b, scores=scores_out)
         else:
@@ -185,7 +200,7 @@ def main():
     n_steps = args.warmup + args.steps
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
     step_idx = [mine[(np.arange(P) + s * P) % len(mine)] for s in range(n_steps)]
-    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev) for ix in step_idx]
+    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev, pitch_align=32 if args.path == "fast" else 16) for ix in step_idx]
     runner = Runner(corpus, batches, m, kappa, args.path, overlap=args.overlap)
     scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
@@ -229,7 +244,7 @@ def main():
                                           for s in range(args.warmup, n_steps)])) for k in range(5)}
     # dominant HBM-bound kernel of the path: the cross-similarity kernel (fused with the sliding
     # window in the fast path, materialising the CSM in the staged path)
-    if args.path == "fast":
+    if args.path in ("fast", "fast_f64"):
         kname, kms, kbytes = "crp_strip_kernel<12,9> (CRPUtils.py:67 + :24 fused, f64 MFMA)", stage_ms["crp"], runner.crp_bytes
     else:
         kname, kms, kbytes = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
@@ -253,7 +268,7 @@ def main():
                      "bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 4)},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
-    if rank == 0 and args.path == "fast":
+    if rank == 0 and args.path in ("fast", "fast_f64"):
         # get_csm as an API (the kernel the north star names) on the same batch, outside the timed
         # region, reported beside the path's own dominant kernel: the plain VALU kernel and the
         # persistent matrix-core strip kernel (bit-identical outputs)

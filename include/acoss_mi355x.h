@@ -185,6 +185,18 @@ int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
 
+/* The same windowed sums (win == 9, d in {12, 13}, float64) in the "split-line" layout: the result occupies
+ * the bytes of the float64 matrix, but every aligned block of 32 values (256 bytes) holds the 32 high words
+ * followed by the 32 low words of the values' order-preserving keys (the IEEE bit pattern with the sign bit
+ * set; the sums are >= +0.0).  Value number idx = crp_off + i * crp_pitch + j of the float64 layout has its
+ * high word at word 64 * (idx / 32) + idx % 32 of `out` and its low word 32 words later.  The kNN selection
+ * (acoss_mask_bits_planar_batch) then reads 4 bytes per element in whole 128-byte lines.  `out` needs the
+ * float64 extent rounded up to a multiple of 32 values; plan the pairs with pitch_align = 32 so that rows
+ * start on block boundaries (other pitches work, slower). */
+int acoss_crp_planar_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                               const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                               uint32_t *out, void *stream);
+
 /* CRPUtils.py:24-45 sliding_csm: S[i][j] = sqrt(sum_{k<win} csm[i+k][j+k]^2), always float64
  * out.  S is written at crp_off with pitch crp_pitch.  1 <= win <= 64. */
 int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,
@@ -226,6 +238,14 @@ int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *de
 size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win);
 int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                           double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);
+
+/* The same bit-packed mask from the split-line form written by acoss_crp_planar_batch_f64 (same work and bits
+ * sizes as acoss_mask_bits_batch).  The row and column selections read only the high words; rows or columns
+ * whose k-th smallest value shares its high word with another element are finished from both words.
+ * Results are identical to acoss_mask_bits_batch on the float64 matrix. */
+int acoss_mask_bits_planar_batch(const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+                                 int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
+                                 void *work, size_t work_bytes, void *stream);
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win,
                            int max_nx, int max_ny, int boundary, const acoss_align_params *params,
                            float *scores, void *stream);

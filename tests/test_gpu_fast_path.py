@@ -164,3 +164,92 @@ def test_bit_mask_path_equals_byte_mask_path(eng, golden):
             for boundary in (0, 1):
                 assert np.array_equal(eng.align_bits("dmax", bits, batch, boundary=boundary).cpu().numpy(),
                                       eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())
+
+
+def _planes_of(T):
+    """Split-line form of a float64 device vector: every block of 32 values -> 32 high words + 32 low words of
+    the order-preserving keys (include/acoss_mi355x.h, acoss_crp_planar_batch_f64)."""
+    import torch
+    n = (T.numel() + 31) & ~31
+    v = torch.zeros(n, dtype=torch.float64, device=T.device)
+    v[:T.numel()] = T
+    b = (v + 0.0).view(torch.int64)
+    key = torch.where(b < 0, ~b, b | (-0x8000000000000000))
+    hi = (key >> 32).to(torch.int32)
+    lo = (key << 32 >> 32).to(torch.int32)
+    return torch.stack([hi.view(-1, 32), lo.view(-1, 32)], dim=1).reshape(-1).contiguous()
+
+
+def _planar_value_words(planes, idx):
+    """(high, low) words of float64 element numbers idx (numpy int64) from a host copy of the split-line buffer."""
+    w = (idx >> 5) * 64 + (idx & 31)
+    return planes[w], planes[w + 32]
+
+
+def test_planar_planes_decode_to_float64_result(eng, golden):
+    """crp_planar writes exactly the bits of crp(): high plane | low plane == key of the float64 value."""
+    import torch
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"]),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32))]
+    for (feats, off, gc, pairs), align in [(c, a) for c in cases for a in (32, 16, 1)]:
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+        eng.oti(corpus, batch)
+        xp = eng.pack_x(corpus, batch)
+        T = eng.crp(corpus, batch, xp)
+        planes = eng.crp_planar(corpus, batch, xp, out=torch.full((2 * eng.planar_elems(batch),), -1, dtype=torch.int32, device=corpus.device)).cpu().numpy()
+        want = _planes_of(T).cpu().numpy()
+        for p in range(batch.K):
+            d = batch.descs[p]
+            M, N = d["nx"] - 8, d["ny"] - 8
+            idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+            gh, gl = _planar_value_words(planes, idx)
+            rh, rl = _planar_value_words(want, idx)
+            assert np.array_equal(gh, rh) and np.array_equal(gl, rl), p
+
+
+def test_planar_mask_equals_float64_mask(eng, golden):
+    """mask_bits_planar == mask_bits: on the golden pairs, on ragged small pairs, and on matrices crafted so
+    that the k-th smallest shares its high word with other elements or is an exact tie (fix-up pass)."""
+    import torch
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"]),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32))]
+    for (feats, off, gc, pairs), align in [(c, a) for c in cases for a in (32, 2, 1)]:
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+        eng.oti(corpus, batch)
+        xp = eng.pack_x(corpus, batch)
+        T = eng.crp(corpus, batch, xp)
+        planes = eng.crp_planar(corpus, batch, xp)
+        for mutual in (True, False):
+            for kappa in (0.095, 0.5, 3, 0):
+                want, _ = eng.mask_bits(T, batch, kappa, mutual=mutual)
+                got, _ = eng.mask_bits_planar(planes, batch, kappa, mutual=mutual)
+                for p in range(batch.K):
+                    assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (p, mutual, kappa)
+    # crafted values on the layout of the golden batch: few distinct high words, many exact ties, negatives
+    corpus = eng.DeviceCorpus(g["feats"], g["frame_off"], gchroma=g["gchroma"])
+    batch = eng.PairBatch(corpus.frame_off, g["pairs"], 9, corpus.device, pitch_align=32)
+    rng = np.random.default_rng(5)
+    n = batch.total_crp
+    crafted = [
+        1.0 + rng.integers(0, 1 << 20, n) * 2.0 ** -52,                      # one high word, distinct low words
+        rng.integers(0, 7, n).astype(np.float64),                             # seven values: ties everywhere
+        np.round(rng.standard_normal(n), 2),                                  # negatives, zeros (+0.0 / -0.0), ties
+        rng.integers(0, 50, n) + rng.integers(0, 4, n) * 2.0 ** -40,          # shared high words near every rank
+    ]
+    for vals in crafted:
+        T = torch.from_numpy(np.ascontiguousarray(vals)).to(corpus.device)
+        planes = _planes_of(T)
+        for mutual in (True, False):
+            want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+            got, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=mutual)
+            assert torch.equal(got, want), mutual
