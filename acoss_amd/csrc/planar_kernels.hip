@@ -217,15 +217,22 @@ __global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32
                 const int pl = min(15 * 64 + lane, N - 1);
                 h[15] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
             } else {
+                // (cold paths: the lane number is laundered through an empty asm so that the sixteen address
+                // computations stay here instead of being hoisted, as 64-bit register pairs, in front of the
+                // row loop -- where they would set the register count of the whole kernel)
+                int lc = lane;
+                asm volatile("" : "+v"(lc));
 #pragma unroll
                 for (int e = 0; e < 16; e++) {
-                    const int pl = min(e * 64 + lane, N - 1);
+                    const int pl = min(e * 64 + lc, N - 1);
                     h[e] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
                 }
             }
         } else {
+            int lc = lane;
+            asm volatile("" : "+v"(lc));
 #pragma unroll
-            for (int e = 0; e < 16; e++) h[e] = Thi[planar_word(idx0 + min(e * 64 + lane, N - 1))];
+            for (int e = 0; e < 16; e++) h[e] = Thi[planar_word(idx0 + min(e * 64 + lc, N - 1))];
         }
         if constexpr (MODE == 1) {
             unsigned acc = 0;
@@ -269,18 +276,26 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
         // 64 rows x 8 column pairs per sweep (8-byte loads, 64-byte row segments), 16 sweeps (M <= 1024).
         // (16-byte loads with 4 lanes per row segment take 2.3x as long: measured.)
         const int c2 = threadIdx.x & 7, rr = threadIdx.x >> 3;
-        const bool vec_ok = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0) && (j0 + PL_COLS <= N);   // block-uniform
+        // block-uniform: rows on 32-value block boundaries and a full column group -> wave-uniform base pointer
+        // + 32-bit word offsets (2 * row * pitch + the column's word inside its row)
+        const bool fast = ((ds.crp_pitch & 31) == 0) && ((ds.crp_off & 31) == 0) && (j0 + PL_COLS <= N);
         uint2 tmp[16];
-        if (vec_ok) {
+        if (fast) {
+            const uint32_t *pb = Thi + 2 * ds.crp_off;
+            const int jc = j0 + 2 * c2;
+            const unsigned cw = (unsigned)(((jc >> 5) << 6) + (jc & 31));
 #pragma unroll
             for (int s = 0; s < 16; s++)
-                tmp[s] = *reinterpret_cast<const uint2 *>(Thi + planar_word(ds.crp_off + (int64_t)min(s * 64 + rr, M - 1) * ds.crp_pitch + j0 + 2 * c2));
+                tmp[s] = *reinterpret_cast<const uint2 *>(pb + ((unsigned)(2 * min(s * 64 + rr, M - 1) * ds.crp_pitch) + cw));
         } else {
+            // (cold path; thread ids laundered so that its address arithmetic is not hoisted: see the row kernel)
+            int cc = c2, rc = rr;
+            asm volatile("" : "+v"(cc), "+v"(rc));
 #pragma unroll
             for (int s = 0; s < 16; s++) {
-                const int64_t ri = ds.crp_off + (int64_t)min(s * 64 + rr, M - 1) * ds.crp_pitch;
-                tmp[s].x = Thi[planar_word(ri + min(j0 + 2 * c2 + 0, N - 1))];
-                tmp[s].y = Thi[planar_word(ri + min(j0 + 2 * c2 + 1, N - 1))];
+                const int64_t ri = ds.crp_off + (int64_t)min(s * 64 + rc, M - 1) * ds.crp_pitch;
+                tmp[s].x = Thi[planar_word(ri + min(j0 + 2 * cc + 0, N - 1))];
+                tmp[s].y = Thi[planar_word(ri + min(j0 + 2 * cc + 1, N - 1))];
             }
         }
 #pragma unroll
