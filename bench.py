@@ -251,6 +251,19 @@ def main():
     kbytes = float(np.mean(kbytes[args.warmup:]))
     achieved = kbytes / (kms * 1e-3) / 1e9
 
+    # HBM bytes per launch of that kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE exact,
+    # FETCH_SIZE x2 on gfx950) -- only quoted when the profile was taken on this very workload
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_planar_pmc.json")
+    pmc_key = {"fast": "crp_strip_kernel<12, 9, false, 0, false, true>"}.get(args.path)
+    if pmc_key and runner.planar and P == 2048 and args.frames == 1000 and os.path.exists(pmc_file):
+        with open(pmc_file) as fh:
+            c = json.load(fh).get(pmc_key)
+        if c and "hbm_write_GB" in c:
+            traffic = round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9)
+            traffic_src = "profiles/r01_planar_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
+    if runner.planar:
+        kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, split-line key words out)"
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
         "value": round(value, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,
@@ -264,7 +277,7 @@ def main():
                    "parallelism": "pair-shard x%d, one all-gather" % world},
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 4)},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
