@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void crp_mfma_kernel(const double *__restrict_
 // Two barriers per step separate ring writes from ring reads.
 // ---------------------------------------------------------------------------------------------
 constexpr int STRIP_ROWS = 32;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // gfx9 raw buffer: 32-bit data format, no swizzle
 
 // MODE (development probes, product = 0): 1 = no result stores, 2 = no window sums (store a C value),
 // 3 = no MFMA phase (stale LDS contents summed)
@@ -457,8 +460,18 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     const int o_pitch = CSM_LAYOUT ? ds.csm_pitch : ds.crp_pitch;
     double *orow = out + o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;
     const bool quad_ok = ((o_pitch & 3) == 0) && ((o_off & 3) == 0) && (TN % 4 == 0);   // block-uniform
-    const int64_t pidx0 = o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;   // float64 index of (first row of the wave, strip column 0)
-    uint32_t *const pwords = reinterpret_cast<uint32_t *>(out);
+    // The pair's result matrix as a raw buffer resource (diagonal-run form): every store is "wave-uniform byte
+    // offset of the row (SGPR) + 32-bit lane offset", so no 64-bit address pairs live in VGPRs, and the hardware
+    // range check drops anything outside the matrix.  Planar: offsets count from the 32-value block that holds
+    // the matrix start.  (Same-process A/B against plain pointer stores: 3.33 vs 3.56 ms float64, 3.83 vs 4.38 ms
+    // planar.)
+    const int o_rows = CSM_LAYOUT ? ds.nx : M;
+    const int64_t pblock0 = o_off & ~(int64_t)31;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        out + (PLANAR ? pblock0 : o_off), 0,
+        (int)(8 * (PLANAR ? (((o_off - pblock0) + (int64_t)o_rows * o_pitch + 31) & ~(int64_t)31) : (int64_t)o_rows * o_pitch)),
+        BUFFER_RSRC_WORD3);
+    const int orow0 = (wave * ROWS_PER_WAVE - HALO) * o_pitch + j0 + (PLANAR ? (int)(o_off - pblock0) : 0);   // element index of (first row of the wave, strip column 0)
     static_assert(!PLANAR || ((TN + ROWS_PER_WAVE <= CRP_CT) && !SQRT_OUT && !CSM_LAYOUT), "planar output: diagonal-run form only");
 
     // x frames are fetched two steps ahead (registers), so their HBM latency spans a whole step
@@ -533,21 +546,26 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     sa = csm_sqrt(sa);
                     sb = csm_sqrt(sb);
                 }
-                double *o = orow + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
                 const int col = dcol + q;
                 if constexpr (PLANAR) {
-                    // high-word address of strip column c of this row (low word: + 32)
-                    // (wave-uniform block base + a 32-bit lane offset: idx = 32 A + u  ->  word 64 A + u + (u & ~31))
-                    const int64_t pidx = pidx0 + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
-                    uint32_t *const rowbase = pwords + ((pidx >> 5) << 6);
-                    const int pb = (int)(pidx & 31);
-                    auto hw = [&](const int c) { const unsigned u = (unsigned)max(pb + c, 0); return rowbase + (u + (u & ~31u)); };   // c < 0: masked lanes
+                    // row start = 32 A + pb (A, pb wave-uniform); strip column c sits u = pb + c values into block A:
+                    // high word at byte 256 A + 4 (u + (u & ~31)), low word 128 bytes later
+                    const int ridx = orow0 + (t * STRIP_ROWS + q) * o_pitch;
+                    const int soff = 8 * (ridx & ~31);
+                    const int pb = ridx & 31;
+                    auto hw = [&](const int c) { const int u = pb + c; return 4 * (u + (u & ~31)); };
                     const uint32_t ha = (uint32_t)__double2hiint(sa) | 0x80000000u, la = (uint32_t)__double2loint(sa);
                     const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u, lb = (uint32_t)__double2loint(sb);
                     if (CHECKED) {
                         const bool row_ok = gi >= 0 && gi < M;
-                        if (row_ok && col >= 0 && col < TN && j0 + col < N) { uint32_t *a = hw(col); a[0] = ha; a[32] = la; }
-                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) { uint32_t *a = hw(col + 1); a[0] = hb; a[32] = lb; }
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) {
+                            __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(la, orsrc, hw(col) + 128, soff, 0);
+                        }
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) {
+                            __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b32(lb, orsrc, hw(col + 1) + 128, soff, 0);
+                        }
                     } else {
                         // this lane's pair of the row: columns ps, ps + 1 (ps even)
                         uint32_t h0 = ha, h1 = hb, l0 = la, l1 = lb;
@@ -579,28 +597,31 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                                 g1 = leader ? a1 : b1;
                             }
                             const int qs = leader ? ps : ps - 2;
-                            const uint4 v = leader ? make_uint4(h0, h1, g0, g1) : make_uint4(g0, g1, l0, l1);
-                            if (qs >= 0 && qs < TN) *reinterpret_cast<uint4 *>(hw(qs) + (leader ? 0 : 32)) = v;
+                            const u32x4_t v = leader ? (u32x4_t){h0, h1, g0, g1} : (u32x4_t){g0, g1, l0, l1};
+                            if (qs >= 0 && qs < TN) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, hw(qs) + (leader ? 0 : 128), soff, 0);
                         } else if (ps >= 0 && ps < TN) {
-                            uint32_t *a = hw(ps);
-                            *reinterpret_cast<uint2 *>(a) = make_uint2(h0, h1);
-                            *reinterpret_cast<uint2 *>(a + 32) = make_uint2(l0, l1);
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, orsrc, hw(ps), soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){l0, l1}, orsrc, hw(ps) + 128, soff, 0);
                         }
                     }
-                } else if (MODE == 1) {
-                    if (sa == -1.25) o[col & 63] = sb;
-                } else if (CHECKED) {
-                    const bool row_ok = gi >= 0 && gi < M;
-                    if (row_ok && col >= 0 && col < TN && j0 + col < N) o[(unsigned)max(col, 0)] = sa;
-                    if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) o[(unsigned)max(col + 1, 0)] = sb;
-                } else if ((q & 1) == 0) {
-                    // (unsigned lane offsets from the wave-uniform row pointer: no 64-bit address registers)
-                    if (col >= 0 && col < TN) *reinterpret_cast<double2 *>(o + (unsigned)max(col, 0)) = make_double2(sa, sb);
                 } else {
-                    const int glo = __builtin_amdgcn_update_dpp(0, __double2loint(sa), 0x130, 0xf, 0xf, true);   // wave_shl:1
-                    const int ghi = __builtin_amdgcn_update_dpp(0, __double2hiint(sa), 0x130, 0xf, 0xf, true);
-                    if (col + 1 >= 0 && col + 1 < TN)
-                        *reinterpret_cast<double2 *>(o + (unsigned)max(col + 1, 0)) = make_double2(sb, __hiloint2double(ghi, glo));
+                    const int soff = 8 * (orow0 + (t * STRIP_ROWS + q) * o_pitch);      // wave-uniform byte offset of (row, strip column 0)
+                    const u32x2_t wa = {(unsigned)__double2loint(sa), (unsigned)__double2hiint(sa)};
+                    const u32x2_t wb = {(unsigned)__double2loint(sb), (unsigned)__double2hiint(sb)};
+                    if (MODE == 1) {
+                        if (sa == -1.25) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * (col & 63), soff, 0);
+                    } else if (CHECKED) {
+                        const bool row_ok = gi >= 0 && gi < M;
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b64(wa, orsrc, 8 * col, soff, 0);
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * col + 8, soff, 0);
+                    } else if ((q & 1) == 0) {
+                        if (col >= 0 && col < TN) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wa.x, wa.y, wb.x, wb.y}, orsrc, 8 * col, soff, 0);
+                    } else {
+                        const unsigned glo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.x, 0x130, 0xf, 0xf, true);   // wave_shl:1
+                        const unsigned ghi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.y, 0x130, 0xf, 0xf, true);
+                        if (col + 1 >= 0 && col + 1 < TN)
+                            __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wb.x, wb.y, glo, ghi}, orsrc, 8 * col + 8, soff, 0);
+                    }
                 }
             }
         } else {
