@@ -463,8 +463,9 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     // The pair's result matrix as a raw buffer resource (diagonal-run form): every store is "wave-uniform byte
     // offset of the row (SGPR) + 32-bit lane offset", so no 64-bit address pairs live in VGPRs, and the hardware
     // range check drops anything outside the matrix.  Planar: offsets count from the 32-value block that holds
-    // the matrix start.  (Same-process A/B against plain pointer stores: 3.33 vs 3.56 ms float64, 3.83 vs 4.38 ms
-    // planar.)
+    // the matrix start.  (Time-neutral against plain pointer stores in a same-buffer A/B -- the strip kernel's
+    // time moves by up to 10 % with the placement of its output allocation, tools/align_probe.py -- but 12-16 fewer
+    // VGPRs.)
     const int o_rows = CSM_LAYOUT ? ds.nx : M;
     const int64_t pblock0 = o_off & ~(int64_t)31;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
