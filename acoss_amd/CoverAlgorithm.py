@@ -307,11 +307,38 @@ class CoverAlgorithm(object):
                 print('Could not clean-up automatically.')
 
     # --------------------------------------------------------------------------------------
-    def getEvalStatistics(self, similarity_type, topsidx=[1, 10, 100, 1000], verbose=True, write_csv=True):
+    def _mate_ranks_device(self, D, cliques):
+        """Sorted ranks of every song's clique mates from the GPU (acoss_eval_ranks): {song: int32 array}."""
+        from . import engine
+        torch = engine.torch
+        lib = engine._lib.load()
+        engine.require_gpu()
+        N = D.shape[0]
+        dev = "cuda:%d" % torch.cuda.current_device()
+        cid = -1 - np.arange(N, dtype=np.int32)                   # songs in no clique: unique ids, no mates
+        mates = np.zeros(N, dtype=np.int64)
+        for c, members in enumerate(cliques):
+            cid[members] = c
+            mates[members] = len(members) - 1
+        off = np.zeros(N + 1, dtype=np.int64)
+        off[1:] = np.cumsum(mates)
+        Dd = torch.from_numpy(np.ascontiguousarray(D, dtype=np.float32)).to(dev)
+        cid_d, off_d = torch.from_numpy(cid).to(dev), torch.from_numpy(off).to(dev)
+        out = torch.zeros(max(int(off[-1]), 1), dtype=torch.int32, device=dev)
+        engine.check(lib.acoss_eval_ranks(engine._ptr(Dd), N, N, engine._ptr(cid_d), engine._ptr(off_d),
+                                          int(mates.max()) if N else 0, engine._ptr(out), engine._stream()), "eval_ranks")
+        return out.cpu().numpy(), off
+
+    def getEvalStatistics(self, similarity_type, topsidx=[1, 10, 100, 1000], verbose=True, write_csv=True,
+                          on_gpu=False):
         """
         MR, MRR, MDR, MAP and Top-X of one similarity type -- the same numbers as
         CoverAlgorithm.py:330-418 (same permutation, same argsort calls and therefore the same
         tie-breaking), with the per-row rank loop (:367-390) done on arrays.
+
+        on_gpu=True takes the ranks of the clique mates from the GPU instead of argsorting every row (the
+        O(N^2 log N) part, hours of Python at N = 15000 in the reference): identical on rows without equal
+        scores; equal scores rank in song-index order there, in introsort's order here.
         """
         D = np.array(self.Ds[similarity_type], dtype=np.float32)
         N = D.shape[0]
@@ -321,20 +348,26 @@ class CoverAlgorithm(object):
         Ks = Ks[order]
         cliques = [cliques[i] for i in order]
         perm = np.array(list(chain(*cliques)), dtype=int)
-        D = D[perm, :]
-        D = D[:, perm]
-        np.fill_diagonal(D, -np.inf)
-        idx = np.argsort(-D, 1)                                   # :362
-        # rank (1-based position in its row's ordering) of every column
-        pos = np.empty_like(idx)
-        pos[np.arange(N)[:, None], idx] = np.arange(1, N + 1)[None, :]
         ranks = np.nan * np.ones(N)
         AllMap = np.nan * np.ones(N)
         starts = np.concatenate([[0], np.cumsum(Ks)[:-1]])
+        if on_gpu:
+            mate_ranks, off = self._mate_ranks_device(D, cliques)
+        else:
+            D = D[perm, :]
+            D = D[:, perm]
+            np.fill_diagonal(D, -np.inf)
+            idx = np.argsort(-D, 1)                               # :362
+            # rank (1-based position in its row's ordering) of every column
+            pos = np.empty_like(idx)
+            pos[np.arange(N)[:, None], idx] = np.arange(1, N + 1)[None, :]
         for start, K in zip(starts, Ks):
             if K < 2:
                 break                                             # :372-375 cliques are sorted by size
-            block = np.sort(pos[start:start + K, start:start + K], axis=1)[:, :-1]   # drop the last = self (:381)
+            if on_gpu:
+                block = np.stack([mate_ranks[off[s]:off[s + 1]] for s in perm[start:start + K]]).astype(np.int64)
+            else:
+                block = np.sort(pos[start:start + K, start:start + K], axis=1)[:, :-1]   # drop the last = self (:381)
             ranks[start:start + K] = block[:, 0]                  # :386
             j = np.arange(1, K, dtype=np.float64)[None, :]
             AllMap[start:start + K] = np.mean(j / block.astype(np.float64), axis=1)    # :388-390

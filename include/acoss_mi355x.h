@@ -266,6 +266,19 @@ int acoss_dmax_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int ma
 int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
                     const acoss_align_params *params, float *scores, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (4) evaluation -- the rank computation of CoverAlgorithm.getEvalStatistics (CoverAlgorithm.py:362-390)
+ * ------------------------------------------------------------------------------------- */
+/* D: device (N x N) float32 score matrix, row pitch row_pitch elements (higher = more similar; the diagonal is
+ * ignored, as the reference sets it to -inf, :360).  clique_id[N]: device, songs with equal ids are versions of
+ * one another.  mate_off[N + 1]: device prefix sums of (clique size - 1) per song.  For every song i the 1-based
+ * ranks of its clique mates in the descending order of row i (the positions np.argsort(-D, 1) would give them,
+ * :362/:381) are written, sorted ascending, to mate_ranks[mate_off[i] .. mate_off[i+1]).  Equal scores rank in
+ * song-index order (the reference's unstable argsort leaves that order unspecified).  max_mates = the largest
+ * clique size - 1 (<= 4096). */
+int acoss_eval_ranks(const float *D, int N, int64_t row_pitch, const int32_t *clique_id, const int64_t *mate_off,
+                     int max_mates, int32_t *mate_ranks, void *stream);
+
 #ifdef __cplusplus
 }
 #endif
