@@ -75,6 +75,10 @@ SIGNATURES = {
     "acoss_align_fused_batch": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp]),
     "acoss_qmax_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
     "acoss_dmax_batch": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    "acoss_ftm2d_scratch_bytes": (_sz, [_i64, _i64, _i]),
+    "acoss_ftm2d_shingles": (_i, [_vp, _vp, _i, _dbl, _dbl, _vp, _sz, _vp, _vp]),
+    "acoss_ftm2d_pairs": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "acoss_ftm2d_gram": (_i, [_vp, _i, _vp, _vp]),
     "acoss_eval_ranks": (_i, [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp]),
     "acoss_swc_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }

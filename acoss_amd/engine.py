@@ -369,6 +369,8 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     Serra09.py:166-175 for every pair, fast path: oti -> pack_x -> crp (fused CSM + sliding window,
     squared) -> mutual binarise -> qmax [-> dmax on qmax's boundary].  Falls back to the staged
     chain for shapes the fused kernel does not cover.  Scores are divided by (M+N).
+    want may also hold "swc": swalignimpconstrained on the same mutual mask (BASELINE config 3; the
+    reference's plugins call it as `swconstrained(B, D, M, N) / (M + N)`, EarlySNF_Old.py:199-203).
     """
     if not crp_supported(corpus, m):
         return serra09_scores_staged(corpus, pairs, m, kappa, do_oti, want, batch_pairs)
@@ -391,6 +393,16 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
             T = torch.empty(planar_elems(batch), dtype=torch.float64, device=corpus.device)
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
         denom = (batch.M + batch.N).astype(np.float64)
+        if "swc" in want:
+            # Smith-Waterman with the -0.5 / -0.7 gap penalties (SequenceAlignment.c:73-99) reads neighbouring mask
+            # bytes in its Delta terms: byte mask + dp_wave_kernel<swc>; the bit-mask kernels cover qmax / dmax
+            crp(corpus, batch, xp, sqrt_out=False, out=T)
+            binarize(T, batch, kappa, mutual=True, out=B, work=work)
+            mats, _ = batch.mats()
+            for kind, kw in (("qmax", {}), ("dmax", {"boundary": 1}), ("swc", {})):
+                if kind in want:
+                    out[kind][lo:lo + len(sel)] = align(kind, B, mats, **kw).cpu().numpy().astype(np.float64) / denom
+            continue
         if planar_supported(corpus, batch):
             # same bytes as T, viewed as the two uint32 planes
             planes = crp_planar(corpus, batch, xp, out=T[:planar_elems(batch)].view(torch.int32))
@@ -455,4 +467,53 @@ def serra09_scores_staged(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("q
             out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
         if keep is not None:
             keep.update(batch=batch, C=C, S=S, B=B)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------
+# FTM2D (benchmarking/FTM2D.py): 2D Fourier transform magnitude shingles and their similarity
+# ---------------------------------------------------------------------------------------------
+def ftm2d_shingles(btchromas, pwr=1.96, C=5):
+    """One 900-d shingle per song (FTM2D.py:92-100) from beat-synchronous chroma: btchromas is a list of
+    (12, nbeats) arrays (what librosa.util.sync returns at :91).  Returns a (n_songs, 900) float64 device tensor;
+    songs with fewer than 75 beats get zeros (:87-90)."""
+    lib = _lib.load()
+    require_gpu()
+    dev = "cuda:%d" % torch.cuda.current_device()
+    n = len(btchromas)
+    nb = np.array([b.shape[1] for b in btchromas], dtype=np.int64)
+    off = np.zeros(n + 1, dtype=np.int64)
+    off[1:] = np.cumsum(nb)
+    for b in btchromas:
+        if b.shape[0] != 12:
+            raise AssertionError('beat-aligned matrix transposed?')          # FTM2D.py:37
+    flat = np.concatenate([np.ascontiguousarray(b.T, dtype=np.float64) for b in btchromas], axis=0) if n else np.zeros((0, 12))
+    bt = torch.from_numpy(np.ascontiguousarray(flat)).to(dev) if flat.size else torch.zeros((1, 12), dtype=torch.float64, device=dev)
+    windows = int(np.maximum(nb - 74, 0).sum())
+    scratch = torch.empty(int(lib.acoss_ftm2d_scratch_bytes(int(off[-1]), windows, n)), dtype=torch.uint8, device=dev)
+    out = torch.empty((n, 900), dtype=torch.float64, device=dev)
+    check(lib.acoss_ftm2d_shingles(_ptr(bt), off.ctypes.data, n, float(pwr), float(C), _ptr(scratch), scratch.numel(),
+                                   _ptr(out), _stream()), "ftm2d_shingles")
+    return out
+
+
+def ftm2d_pairs(shingles, pairs):
+    """exp(-|s_i - s_j|^2) for the listed pairs (FTM2D.py:117-127): float64 ndarray(K)."""
+    lib = _lib.load()
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    K = pairs.shape[0]
+    if K == 0:
+        return np.zeros(0)
+    pd = torch.from_numpy(pairs).to(shingles.device)
+    out = torch.empty(K, dtype=torch.float64, device=shingles.device)
+    check(lib.acoss_ftm2d_pairs(_ptr(shingles), _ptr(pd), K, _ptr(out), _stream()), "ftm2d_pairs")
+    return out.cpu().numpy()
+
+
+def ftm2d_gram(shingles):
+    """All n x n similarities as one product on the float64 matrix cores: (n, n) float64 device tensor."""
+    lib = _lib.load()
+    n = shingles.shape[0]
+    out = torch.empty((n, n), dtype=torch.float64, device=shingles.device)
+    check(lib.acoss_ftm2d_gram(_ptr(shingles), n, _ptr(out), _stream()), "ftm2d_gram")
     return out

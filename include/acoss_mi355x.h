@@ -279,6 +279,25 @@ int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max
 int acoss_eval_ranks(const float *D, int N, int64_t row_pitch, const int32_t *clique_id, const int64_t *mate_off,
                      int max_mates, int32_t *mate_ranks, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (5) FTM2D -- the 2D-Fourier-transform-magnitude feature and its similarity (benchmarking/FTM2D.py)
+ * ------------------------------------------------------------------------------------- */
+/* btchroma: device, beat-synchronous chroma of all songs, beats-major (total_beats x 12) float64 (the transpose of
+ * what FTM2D.py:91 produces per song); beat_off[n_songs + 1]: HOST array of first beats.  Per song: chrompwr (:9-25,
+ * power `pwr`), |fft2| of every 12 x 75 window with fftshift (:29-48), per-window L2 norm and log(C x / norm + 1)
+ * (:95-97), median over the windows (:98), L2 normalisation (:99) -> shingles[n_songs][900] (device); zeros for
+ * songs with fewer than 75 beats (:87-90).  Up to 2122 beats per song.  scratch: device,
+ * acoss_ftm2d_scratch_bytes(total_beats, total_windows, n_songs) bytes with total_windows = sum of
+ * max(0, nbeats - 74).  Synchronises `stream` before returning. */
+size_t acoss_ftm2d_scratch_bytes(int64_t total_beats, int64_t total_windows, int n_songs);
+int acoss_ftm2d_shingles(const double *btchroma, const int64_t *beat_off, int n_songs, double pwr, double C,
+                         void *scratch, size_t scratch_bytes, double *shingles, void *stream);
+/* FTM2D.similarity (:117-127): sims[k] = exp(-|s_i - s_j|^2) for pairs[k] = (i, j); all device pointers. */
+int acoss_ftm2d_pairs(const double *shingles, const int32_t *pairs, int K, double *sims, void *stream);
+/* The same for all n x n pairs as one 900-deep product on the float64 matrix cores:
+ * sims[i][j] = exp(-max(0, |s_i|^2 + |s_j|^2 - 2 s_i.s_j)). */
+int acoss_ftm2d_gram(const double *shingles, int n, double *sims, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

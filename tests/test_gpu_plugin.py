@@ -86,3 +86,33 @@ def test_feature_files_and_downsampling(orc, tmp_path):
         exp_q[t], exp_d[t] = orc.serra09_pair(fi["chroma"].T, fi["gchroma"], fj["chroma"].T, fj["gchroma"], m=9, kappa=0.095)
     assert np.array_equal(sims["chroma_qmax"], exp_q), (sims["chroma_qmax"], exp_q)
     assert np.array_equal(sims["chroma_dmax"], exp_d), (sims["chroma_dmax"], exp_d)
+
+
+def test_config3_shape_smith_waterman_chain(orc):
+    """BASELINE config 3 (DA-TACOS benchmark_subset shape: lengths ~N(520,120) in [200,1200], Smith-Waterman
+    constrained on the mutual mask): engine chain vs the oracle composed stage by stage.  qmax / dmax exact, the
+    Smith-Waterman score within 1e-5 (its -0.7 penalty is inexact in float32)."""
+    from acoss_amd import engine, synth
+    engine.require_gpu()
+    lens_it = iter([200, 1200, 520, 640, 1100, 333, 415, 777, 560, 999, 250, 480])       # the clip limits and in between
+    ch = synth.make_corpus(4, 3, seed=15000, lengths=lambda r: next(lens_it))
+    rng = np.random.default_rng(0)
+    allp = synth.all_pairs(ch.n_songs)
+    pairs = allp[rng.permutation(len(allp))[:40]]
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    got = engine.serra09_scores(corpus, pairs, want=("qmax", "dmax", "swc"))
+    lens = np.diff(ch.frame_off)
+    assert lens.min() == 200 and lens.max() == 1200
+    for t, (i, j) in enumerate(pairs):
+        X, Y = ch.song(i), ch.song(j)
+        oti = orc.get_oti(ch.gchroma[i], ch.gchroma[j])
+        S = orc.sliding_csm(orc.get_csm(X, Y, oti), 9)
+        B = orc.csm_to_binary_mutual(S, 0.095)
+        M, N = B.shape
+        Bf = np.ascontiguousarray(B.flatten())
+        D = np.zeros(M * N, dtype=np.float32)
+        q = orc.qmax(Bf, D, M, N) / (M + N)
+        d = orc.dmax(Bf, D, M, N) / (M + N)                        # D not re-zeroed (Serra09.py:173-175)
+        sw = orc.swconstrained(Bf, np.zeros((M + 1) * (N + 1), dtype=np.float32), M, N) / (M + N)
+        assert got["qmax"][t] == q and got["dmax"][t] == d, (t, i, j)
+        assert abs(got["swc"][t] - sw) <= 1e-5, (t, i, j, got["swc"][t], sw)

@@ -159,3 +159,22 @@ def test_evalstats(golden):
             cliques.setdefault("clique_%d" % lab, set()).add(i)
         MR, MRR, MDR, MAP, tops = get_eval_statistics(g["e%d_D" % c], cliques)
         assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["e%d_stats" % c])
+
+
+def test_ftm2d_oracle_against_reference_functions(golden):
+    """oracle/ftm2d.py vs the reference's chrompwr / btchroma_to_fftmat / shingle / similarity outputs."""
+    from oracle import ftm2d
+    g = golden("ftm2d")
+    n = int(g["n_songs"])
+    sh = []
+    for s in range(n):
+        X = g["bt%d" % s]
+        if "chrompwr%d" % s in g.files:
+            assert np.array_equal(ftm2d.chrompwr(X, 1.96), g["chrompwr%d" % s])
+            # numpy's pocketfft vs scipy.fftpack: same transform, last-bit differences
+            np.testing.assert_allclose(ftm2d.btchroma_to_fftmat(g["chrompwr%d" % s], 75), g["fftmat%d" % s], rtol=0, atol=1e-12)
+        sh.append(ftm2d.shingle_from_btchroma(X))
+        np.testing.assert_allclose(sh[-1], g["shingle%d" % s], rtol=0, atol=1e-13)
+    sims = np.array([ftm2d.similarity(sh[i], sh[j]) for i, j in g["pairs"]])
+    np.testing.assert_allclose(sims, g["sims"], rtol=0, atol=1e-13)
+    assert np.array_equal(ftm2d.shingle_from_btchroma(np.ones((12, 74))), np.zeros(900))     # too few beats (:89)
