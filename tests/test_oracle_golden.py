@@ -178,3 +178,34 @@ def test_ftm2d_oracle_against_reference_functions(golden):
     sims = np.array([ftm2d.similarity(sh[i], sh[j]) for i, j in g["pairs"]])
     np.testing.assert_allclose(sims, g["sims"], rtol=0, atol=1e-13)
     assert np.array_equal(ftm2d.shingle_from_btchroma(np.ones((12, 74))), np.zeros(900))     # too few beats (:89)
+
+
+def test_snf_oracle_against_reference(golden):
+    """oracle/snf.py vs SimilarityFusion.py's own outputs (affinities, P, S, cross-diffusion) and the EarlySNF chain."""
+    from oracle import snf
+    g = golden("snf")
+    tol = dict(rtol=0, atol=1e-12)
+    np.testing.assert_allclose(snf.get_W(g["u_ssma"], 4), g["u_W_ssma"], **tol)
+    np.testing.assert_allclose(snf.get_WCSM(g["u_csm"], 4, 5), g["u_WCSM"], **tol)
+    W = snf.get_WCSMSSM(g["u_ssma"], g["u_ssmb"], g["u_csm"], 9)
+    np.testing.assert_allclose(W, g["u_W"], **tol)
+    np.testing.assert_allclose(snf.get_P(g["u_W"], True), g["u_P"], **tol)
+    np.testing.assert_allclose(snf.get_P(g["u_W"], False), g["u_P_noreg"], **tol)
+    np.testing.assert_allclose(snf.get_S(g["u_W"], 9), g["u_S"], **tol)
+    for it in (1, 2, 3):
+        np.testing.assert_allclose(snf.snf_ws([g["u_W"], g["u_W2"]], K=9, niters=it), g["u_fused_it%d" % it], **tol)
+    # the chain, pair 0 with intermediates, then all scores
+    off = g["c_frame_off"]
+    songs = [{'gchroma': g["c_gchroma"][s], 'chroma': np.ascontiguousarray(g["c_feats"][off[s]:off[s + 1]].T),
+              'ssms': g["c_ssms%d" % s]} for s in range(len(off) - 1)]
+    keep = {}
+    q, d = [], []
+    for t, (i, j) in enumerate(g["c_pairs"]):
+        a, b = snf.early_snf_pair(songs[i], songs[j], keep=keep if t == 0 else None)
+        q.append(a); d.append(b)
+    np.testing.assert_allclose(keep["csm"], g["c0_csm"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(keep["W0"], g["c0_W0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(keep["W1"], g["c0_W1"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(keep["fused"], g["c0_fused"], rtol=0, atol=1e-11)
+    assert np.array_equal(keep["B"], g["c0_B"])
+    assert np.array_equal(np.array(q), g["c_snf_qmax"]) and np.array_equal(np.array(d), g["c_snf_dmax"])
