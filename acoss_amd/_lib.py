@@ -79,6 +79,8 @@ SIGNATURES = {
     "acoss_ftm2d_shingles": (_i, [_vp, _vp, _i, _dbl, _dbl, _vp, _sz, _vp, _vp]),
     "acoss_ftm2d_pairs": (_i, [_vp, _vp, _i, _vp, _vp]),
     "acoss_ftm2d_gram": (_i, [_vp, _i, _vp, _vp]),
+    "acoss_snf_scratch_bytes": (_sz, [_vp, _vp, _i, _i]),
+    "acoss_snf_cross_batch": (_i, [_vp, _i, _i, _vp, _vp, _dbl, _dbl, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "acoss_eval_ranks": (_i, [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp]),
     "acoss_swc_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }

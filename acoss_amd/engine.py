@@ -517,3 +517,92 @@ def ftm2d_gram(shingles):
     out = torch.empty((n, n), dtype=torch.float64, device=shingles.device)
     check(lib.acoss_ftm2d_gram(_ptr(shingles), n, _ptr(out), _stream()), "ftm2d_gram")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# Early similarity network fusion (benchmarking/EarlySNF.py:41-90, SimilarityFusion.py)
+# ---------------------------------------------------------------------------------------------
+class _SnfFeature(ctypes.Structure):
+    _fields_ = [("ssma", ctypes.c_void_p), ("ssmb", ctypes.c_void_p), ("csm", ctypes.c_void_p),
+                ("da", ctypes.c_void_p), ("db", ctypes.c_void_p), ("dc", ctypes.c_void_p), ("win", ctypes.c_int32)]
+
+
+def snf_cross(features, M, N, kappa, dout, out=None, niters=3, mu=0.5, debug=False):
+    """-fused[0:M, M:] of every pair (EarlySNF.py:83-85) from per-feature distance matrices.
+    features: list of dicts {ssma, ssmb, csm: float64 device buffers; da, db, dc: PairBatch (layouts); win}.
+    M, N: int arrays (K).  dout: PairBatch whose crp layout receives the result (float64 buffer `out`).
+    debug=True also returns (W [n_feat][sum L^2], fused [sum L^2]) device tensors."""
+    lib = _lib.load()
+    K = len(M)
+    M = np.ascontiguousarray(M, dtype=np.int32)
+    N = np.ascontiguousarray(N, dtype=np.int32)
+    dev = dout.descs_dev.device
+    arr = (_SnfFeature * len(features))()
+    for f, ft in enumerate(features):
+        arr[f].ssma, arr[f].ssmb, arr[f].csm = _ptr(ft["ssma"]), _ptr(ft["ssmb"]), _ptr(ft["csm"])
+        arr[f].da, arr[f].db, arr[f].dc = _ptr(ft["da"].descs_dev), _ptr(ft["db"].descs_dev), _ptr(ft["dc"].descs_dev)
+        arr[f].win = int(ft["win"])
+    need = int(lib.acoss_snf_scratch_bytes(M.ctypes.data, N.ctypes.data, K, len(features)))
+    scratch = torch.empty(need, dtype=torch.uint8, device=dev)
+    if out is None:
+        out = torch.zeros(max(dout.total_crp, 1), dtype=torch.float64, device=dev)
+    tot = int(((M.astype(np.int64) + N) ** 2).sum())
+    dW = torch.empty((len(features), tot), dtype=torch.float64, device=dev) if debug else None
+    dF = torch.empty(tot, dtype=torch.float64, device=dev) if debug else None
+    check(lib.acoss_snf_cross_batch(ctypes.addressof(arr), len(features), K, M.ctypes.data, N.ctypes.data, float(kappa),
+                                    float(mu), int(niters), _ptr(scratch), need, _ptr(dout.descs_dev), _ptr(out),
+                                    _ptr(dW) if debug else None, _ptr(dF) if debug else None, _stream()), "snf_cross_batch")
+    return (out, dW, dF) if debug else out
+
+
+def early_snf_scores(chroma, ssms, pairs, m=9, kappa=0.095, do_oti=True, batch_pairs=None, want=("qmax", "dmax")):
+    """
+    EarlySNF.py:41-90 for every pair: the chroma block affinity (CSM and both SSMs with the sliding window) and the
+    'ssms' feature block affinity (no window) are fused by 3 cross-diffusion steps; the negated cross block goes
+    through the mutual kNN mask and qmax [/ dmax on the same D].  chroma: DeviceCorpus of (n, 12) frames;
+    ssms: DeviceCorpus of the per-song (n - m + 1, d) features.  Scores are divided by (M + N).
+    """
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+    K = pairs.shape[0]
+    out = {k: np.zeros(K) for k in want}
+    if K == 0:
+        return out
+    if batch_pairs is None:
+        L = 2.0 * float(chroma.lengths().max())
+        batch_pairs = int(max(1, min(K, (24 << 30) // max(8.5 * 8.0 * L * L, 1.0))))
+    dev = chroma.device
+    for lo in range(0, K, batch_pairs):
+        sel = pairs[lo:lo + batch_pairs]
+        aa = np.stack([sel[:, 0], sel[:, 0]], axis=1)
+        bb = np.stack([sel[:, 1], sel[:, 1]], axis=1)
+        feats = []
+        # chroma: windowed distances, OTI on the cross pair only (a common roll does not change the self distances)
+        bc, ba, bbb = (PairBatch(chroma.frame_off, q, m, dev) for q in (sel, aa, bb))
+        if do_oti:
+            oti(chroma, bc)
+        mats = []
+        for b in (ba, bbb, bc):
+            xp = pack_x(chroma, b)
+            mats.append(crp(chroma, b, xp, sqrt_out=True))
+        feats.append(dict(ssma=mats[0], ssmb=mats[1], csm=mats[2], da=ba, db=bbb, dc=bc, win=m))
+        # 'ssms' features: plain Euclidean distances (get_csm / get_ssm, EarlySNF.py:72-74)
+        sc, sa, sb = (PairBatch(ssms.frame_off, q, 1, dev) for q in (sel, aa, bb))
+        feats.append(dict(ssma=csm(ssms, sa), ssmb=csm(ssms, sb), csm=csm(ssms, sc), da=sa, db=sb, dc=sc, win=1))
+        if not (np.array_equal(sc.descs["nx"], bc.M) and np.array_equal(sc.descs["ny"], bc.N)):
+            raise AcossError("early_snf: the 'ssms' features must have nframes - m + 1 rows per song")
+        cross = snf_cross(feats, bc.M, bc.N, kappa, bc)
+        denom = (bc.M + bc.N).astype(np.float64)
+        if bits_path_supported(bc):
+            bits, _ = mask_bits(cross, bc, kappa, mutual=True)
+            if "qmax" in want:
+                out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, bc).cpu().numpy().astype(np.float64) / denom
+            if "dmax" in want:
+                out["dmax"][lo:lo + len(sel)] = align_bits("dmax", bits, bc, boundary=1).cpu().numpy().astype(np.float64) / denom
+        else:
+            B = binarize(cross, bc, kappa, mutual=True)
+            mats_d, _ = bc.mats()
+            if "qmax" in want:
+                out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats_d).cpu().numpy().astype(np.float64) / denom
+            if "dmax" in want:
+                out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats_d, boundary=1).cpu().numpy().astype(np.float64) / denom
+    return out

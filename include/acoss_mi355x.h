@@ -298,6 +298,31 @@ int acoss_ftm2d_pairs(const double *shingles, const int32_t *pairs, int K, doubl
  * sims[i][j] = exp(-max(0, |s_i|^2 + |s_j|^2 - 2 s_i.s_j)). */
 int acoss_ftm2d_gram(const double *shingles, int n, double *sims, void *stream);
 
+/* ---------------------------------------------------------------------------------------
+ * (6) similarity network fusion of a pair's block affinity matrices (benchmarking/SimilarityFusion.py,
+ *     driven by benchmarking/EarlySNF.py:41-90)
+ * ------------------------------------------------------------------------------------- */
+/* One feature of the fusion: for every pair p the self-similarity matrices of song A (M x M, layout da[p]) and
+ * song B (N x N, db[p]) and their cross-similarity matrix (M x N, dc[p]); the layouts are the crp_off / crp_pitch
+ * fields of pair descriptors (e.g. planned for the pair lists (i, i), (j, j) and (i, j)).  All device pointers. */
+typedef struct acoss_snf_feature {
+    const double *ssma, *ssmb, *csm;
+    const acoss_pair_desc *da, *db, *dc;
+    int32_t win;                 /* unused by the kernels; the embedding window the matrices were built with */
+} acoss_snf_feature;
+
+/* For every pair: W_f = get_WCSMSSM(ssma, ssmb, csm, K) per feature (SimilarityFusion.py:94-134) with
+ * K = int(kappa * (M + N)) (EarlySNF.py:51), snf_ws(Ws, K, niters, reg_diag=True) (:207-277), and
+ * cross_out = -fused[0:M, M:] (EarlySNF.py:84-85) in the layout dout[p] (crp_off / crp_pitch), ready for
+ * acoss_mask_bits_batch / acoss_binarize_batch.  feats, M, N: HOST arrays (n_feat, K, K); M + N <= 2048.
+ * debug_W (n_feat x sum L^2) / debug_fused (sum L^2): optional device buffers receiving the affinity matrices and
+ * the fused matrix, pair after pair, L x L row-major (tests).  Synchronises `stream` before returning. */
+size_t acoss_snf_scratch_bytes(const int32_t *M, const int32_t *N, int K, int n_feat);
+int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, const int32_t *M, const int32_t *N,
+                          double kappa, double mu, int niters, void *scratch, size_t scratch_bytes,
+                          const acoss_pair_desc *dout, double *cross_out, double *debug_W, double *debug_fused,
+                          void *stream);
+
 #ifdef __cplusplus
 }
 #endif

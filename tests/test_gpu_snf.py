@@ -1,0 +1,66 @@
+"""Similarity network fusion / EarlySNF on the GPU against the reference's own outputs
+(tests/golden/snf.npz, made by tests/golden/make_golden_snf.py from SimilarityFusion.py / CRPUtils.py / the compiled
+SequenceAlignment.c) and against the oracle restatement."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from acoss_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _layout(eng, lens, pairs):
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    return eng.PairBatch(off, np.array(pairs, dtype=np.int32), 1, "cuda:0")
+
+
+def _place(batch, mats):
+    import torch
+    buf = np.zeros(max(batch.total_crp, 1))
+    for p, A in enumerate(mats):
+        d = batch.descs[p]
+        view = buf[int(d["crp_off"]):int(d["crp_off"]) + A.shape[0] * int(d["crp_pitch"])].reshape(A.shape[0], -1)
+        view[:, :A.shape[1]] = A
+    return torch.from_numpy(buf).cuda()
+
+
+def test_affinity_and_fusion_match_reference(eng, golden):
+    """get_WCSMSSM and snf_ws (1, 2, 3 iterations) from given distance matrices."""
+    g = golden("snf")
+    M, N = g["u_ssma"].shape[0], g["u_ssmb"].shape[0]
+    la, lb, lc = _layout(eng, [M, N], [(0, 0)]), _layout(eng, [M, N], [(1, 1)]), _layout(eng, [M, N], [(0, 1)])
+    feats = []
+    for pre in ("u", "u2"):
+        feats.append(dict(ssma=_place(la, [g[pre + "_ssma"]]), ssmb=_place(lb, [g[pre + "_ssmb"]]), csm=_place(lc, [g[pre + "_csm"]]),
+                          da=la, db=lb, dc=lc, win=1))
+    L = M + N
+    # K = int(kappa * L) must be 9 as in the fixture
+    kappa = 9.5 / L
+    for it in (1, 2, 3):
+        cross, W, fused = eng.snf_cross(feats, [M], [N], kappa, lc, niters=it, debug=True)
+        W = W.cpu().numpy().reshape(2, L, L)
+        np.testing.assert_allclose(W[0], g["u_W"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(W[1], g["u_W2"], rtol=0, atol=1e-12)
+        fused = fused.cpu().numpy().reshape(L, L)
+        np.testing.assert_allclose(fused, g["u_fused_it%d" % it], rtol=0, atol=1e-12)
+        d = lc.descs[0]
+        got = cross.cpu().numpy()[int(d["crp_off"]):int(d["crp_off"]) + M * int(d["crp_pitch"])].reshape(M, -1)[:, :N]
+        np.testing.assert_allclose(got, -g["u_fused_it%d" % it][0:M, M:], rtol=0, atol=1e-12)
+
+
+def test_early_snf_chain_matches_reference(eng, golden):
+    """EarlySNF.py:41-90 end to end on the fixture's ragged pairs: snf_qmax / snf_dmax equal the reference's."""
+    g = golden("snf")
+    off = g["c_frame_off"]
+    n = len(off) - 1
+    chroma = eng.DeviceCorpus(g["c_feats"], off, gchroma=g["c_gchroma"])
+    ss = [g["c_ssms%d" % s] for s in range(n)]
+    soff = np.concatenate([[0], np.cumsum([x.shape[0] for x in ss])]).astype(np.int64)
+    ssms = eng.DeviceCorpus(np.concatenate(ss, axis=0), soff)
+    res = eng.early_snf_scores(chroma, ssms, g["c_pairs"])
+    assert np.array_equal(res["qmax"], g["c_snf_qmax"]) and np.array_equal(res["dmax"], g["c_snf_dmax"])
