@@ -64,3 +64,38 @@ def test_early_snf_chain_matches_reference(eng, golden):
     ssms = eng.DeviceCorpus(np.concatenate(ss, axis=0), soff)
     res = eng.early_snf_scores(chroma, ssms, g["c_pairs"])
     assert np.array_equal(res["qmax"], g["c_snf_qmax"]) and np.array_equal(res["dmax"], g["c_snf_dmax"])
+
+
+def test_plugin_contract_against_oracle(eng, tmp_path, monkeypatch):
+    """EarlySNF class on feature files with chroma + mfcc + 'ssms': all eight score vectors against the oracle chain."""
+    from oracle import oracle as orc, snf as osnf
+    from acoss_amd.EarlySNF import EarlySNF
+    from acoss_amd import synth
+    monkeypatch.chdir(tmp_path)
+    rng = np.random.default_rng(8)
+    lens = iter([64, 81, 100, 73, 90])
+    ch = synth.make_corpus(5, 1, seed=5, lengths=lambda r: next(lens))
+    d = tmp_path / "feats"
+    d.mkdir()
+    songs = []
+    for i in range(ch.n_songs):
+        X = ch.song(i)                                       # (n, 12) at the aggregated rate: downsample_fac = 1
+        n = X.shape[0]
+        mf = np.cumsum(rng.standard_normal((13, n)), axis=1)
+        ss = np.cumsum(rng.standard_normal((n - 8, 30)), axis=0) * 0.1
+        np.savez(d / ("s%02d.npz" % i), crema=X, mfcc_htk=mf, ssms=ss, label="clique_%d" % (i // 2), track_id="t%d" % i)
+        songs.append({'gchroma': orc.global_chroma(X), 'chroma': np.ascontiguousarray(X.T), 'mfcc': mf, 'ssms': ss})
+    alg = EarlySNF(datapath=str(d), chroma_type="crema", shortname="t", downsample_fac=1, cachedir=str(tmp_path / "cache"))
+    idxs = np.array([[0, 1], [1, 2], [2, 4], [3, 0], [4, 3]])
+    res = alg.similarity(idxs)
+    assert sorted(res) == sorted(EarlySNF.KEYS)
+    for t, (i, j) in enumerate(idxs):
+        q, dm = osnf.early_snf_pair(songs[i], songs[j])
+        assert res["snf_qmax"][t] == q and res["snf_dmax"][t] == dm, (t, res["snf_qmax"][t], q)
+        q, dm = orc.serra09_pair(songs[i]['chroma'].T, songs[i]['gchroma'], songs[j]['chroma'].T, songs[j]['gchroma'])
+        assert res["chroma_qmax"][t] == q and res["chroma_dmax"][t] == dm
+        q, dm = orc.serra09_pair(songs[i]['mfcc'].T, np.zeros(13), songs[j]['mfcc'].T, np.zeros(13), do_oti=False)
+        assert res["mfcc_qmax"][t] == q and res["mfcc_dmax"][t] == dm
+        q, dm = orc.serra09_pair(songs[i]['ssms'], np.zeros(30), songs[j]['ssms'], np.zeros(30), m=1, do_oti=False)
+        assert res["ssms_scatter_qmax"][t] == q and res["ssms_scatter_dmax"][t] == dm
+    assert np.allclose(alg.Ds["snf_qmax"][idxs[:, 0], idxs[:, 1]], res["snf_qmax"])
