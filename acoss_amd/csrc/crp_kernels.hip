@@ -4,6 +4,7 @@
 // gfx950 (CDNA4) only: wave64, DPP reductions, scalar (SGPR) broadcast of wave-uniform rows.
 #include "common.h"
 #include "wave_ops.h"
+#include "gemm_f64.h"
 #include "kernel_utils.h"
 #include "thresh_work.h"
 
@@ -211,6 +212,35 @@ __global__ __launch_bounds__(256) void csm_generic_kernel(const T *__restrict__ 
     }
     const T c = fma((T)-2, acc, norms[ds.x_row0 + i] + norms[ds.y_row0 + j]);
     out[ds.csm_off + (int64_t)i * ds.csm_pitch + j] = clamp_sqrt(c);
+}
+
+// float64 features of any width on the matrix cores (the 20 736-dimensional scattering features of Serra09.py:187,
+// the 'ssms' blocks of EarlySNF.py:72-74): one 128 x 128 tile per block (gemm_f64.h), accumulating in feature
+// order -- the same FMA chain as csm_generic_kernel, so the two agree bit for bit.
+__global__ __launch_bounds__(GM_THREADS) void csm_gemm_kernel(const double *__restrict__ feats, const double *__restrict__ norms,
+                                                              int d, const acoss_pair_desc *__restrict__ descs,
+                                                              int tiles_m, int tiles_n, double *__restrict__ out)
+{
+    __shared__ GemmSmem sm;
+    const int tiles = tiles_m * tiles_n;
+    const int p = blockIdx.x / tiles, t = blockIdx.x % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int i0 = (t / tiles_n) * GM_T, j0 = (t % tiles_n) * GM_T;
+    if (i0 >= ds.nx || j0 >= ds.ny) return;
+    gemm_nt_tile_f64(
+        sm, d,
+        [&](const int r, const int k) {
+            int src = k - ds.shift;                    // np.roll(chroma_i, oti) (Serra09.py:167)
+            if (src < 0) src += d;
+            return (i0 + r < ds.nx && k < d) ? feats[(ds.x_row0 + i0 + r) * d + src] : 0.0;
+        },
+        [&](const int r, const int k) { return (j0 + r < ds.ny && k < d) ? feats[(ds.y_row0 + j0 + r) * d + k] : 0.0; },
+        [&](const int i, const int j, const double v) {
+            if (i0 + i < ds.nx && j0 + j < ds.ny) {
+                const double c = fma(-2.0, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
+                out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
+            }
+        });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -767,6 +797,15 @@ static int launch_csm(const T *feats, const T *norms, int d, const acoss_pair_de
         else
             hipLaunchKernelGGL((csm_kernel<T, 13>), dim3((unsigned)blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
         return launch_check("csm_kernel");
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (d >= 32) {        // wide float64 features: matrix cores
+            const int tm = ceil_div(max_nx, GM_T), tn = ceil_div(max_ny, GM_T);
+            const int64_t blocks = (int64_t)K * tm * tn;
+            if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
+            hipLaunchKernelGGL(csm_gemm_kernel, dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, feats, norms, d, descs, tm, tn, csm);
+            return launch_check("csm_gemm_kernel");
+        }
     }
     const int tm = ceil_div(max_nx, 16), tn = ceil_div(max_ny, 16);
     const int64_t blocks = (int64_t)K * tm * tn;

@@ -13,6 +13,7 @@
 // multiply-adds.
 #include "common.h"
 #include "wave_ops.h"
+#include "gemm_f64.h"
 
 namespace acoss {
 
@@ -181,68 +182,32 @@ __global__ __launch_bounds__(256) void ftm2d_pairs_kernel(const double *__restri
     if (lane == 0) sims[p] = exp(-d);
 }
 
-// ---- all pairs: exp(-(|a|^2 + |b|^2 - 2 a.b)) on v_mfma_f64_16x16x4_f64 ----------------------------------------
-// Block tile 64 x 64 (4 waves, 32 x 32 each = 2 x 2 MFMA tiles), K walked in chunks of 36 staged through LDS.
-typedef double v4f64_ft __attribute__((ext_vector_type(4)));
-constexpr int FG_T = 64, FG_KC = 36, FG_LD = FG_KC + 1;
-
-__global__ __launch_bounds__(256) void ftm2d_gram_kernel(const double *__restrict__ S, int n, double *__restrict__ out)
+// ---- all pairs: exp(-(|a|^2 + |b|^2 - 2 a.b)) on v_mfma_f64_16x16x4_f64 (gemm_f64.h), norms from a pre-pass ---------
+__global__ __launch_bounds__(256) void ftm2d_norms_kernel(const double *__restrict__ S, int n, double *__restrict__ norms)
 {
-    __shared__ double As[FG_T][FG_LD], Bs[FG_T][FG_LD];
-    __shared__ double na[FG_T], nb[FG_T];
-    const int i0 = blockIdx.y * FG_T, j0 = blockIdx.x * FG_T;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    v4f64_ft acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (v4f64_ft){0.0, 0.0, 0.0, 0.0};
-    double nacc = 0.0;      // squared norm of row (threadIdx.x & 63) of A (threads 0..63) / B (threads 64..127)
-    for (int k0 = 0; k0 < FT_DIM; k0 += FG_KC) {
-        for (int e = threadIdx.x; e < FG_T * FG_KC; e += 256) {
-            const int r = e / FG_KC, c = e % FG_KC;
-            As[r][c] = S[(int64_t)min(i0 + r, n - 1) * FT_DIM + k0 + c];
-            Bs[r][c] = S[(int64_t)min(j0 + r, n - 1) * FT_DIM + k0 + c];
-        }
-        __syncthreads();
-        if (threadIdx.x < 128) {
-            const double (*T)[FG_LD] = threadIdx.x < 64 ? As : Bs;
-            for (int c = 0; c < FG_KC; c++) nacc = fma(T[lane][c], T[lane][c], nacc);
-        }
-#pragma unroll
-        for (int kk = 0; kk < FG_KC; kk += 4) {
-            double a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                a[t] = As[wi + 16 * t + lr][kk + lk];
-                b[t] = Bs[wj + 16 * t + lr][kk + lk];
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n) return;
+    double a = 0.0;
+    for (int e = lane; e < FT_DIM; e += 64) a = fma(S[(int64_t)s * FT_DIM + e], S[(int64_t)s * FT_DIM + e], a);
+    for (int d = 32; d > 0; d >>= 1) a += __shfl_down(a, d, 64);
+    if (lane == 0) norms[s] = a;
+}
+
+__global__ __launch_bounds__(GM_THREADS) void ftm2d_gram_kernel(const double *__restrict__ S, const double *__restrict__ norms,
+                                                                int n, double *__restrict__ out)
+{
+    __shared__ GemmSmem sm;
+    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
+    gemm_nt_tile_f64(
+        sm, FT_DIM,
+        [&](const int r, const int k) { return (i0 + r < n && k < FT_DIM) ? S[(int64_t)(i0 + r) * FT_DIM + k] : 0.0; },
+        [&](const int r, const int k) { return (j0 + r < n && k < FT_DIM) ? S[(int64_t)(j0 + r) * FT_DIM + k] : 0.0; },
+        [&](const int i, const int j, const double v) {
+            if (i0 + i < n && j0 + j < n) {
+                const double d = fmax(fma(-2.0, v, norms[i0 + i] + norms[j0 + j]), 0.0);
+                out[(int64_t)(i0 + i) * n + j0 + j] = exp(-d);
             }
-#pragma unroll
-            for (int ta = 0; ta < 2; ta++)
-#pragma unroll
-                for (int tb = 0; tb < 2; tb++)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < 64) na[lane] = nacc;
-    else if (threadIdx.x < 128) nb[lane] = nacc;
-    __syncthreads();
-#pragma unroll
-    for (int ta = 0; ta < 2; ta++)
-#pragma unroll
-        for (int tb = 0; tb < 2; tb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int li = wi + 16 * ta + lk + 4 * r, lj = wj + 16 * tb + lr;       // C element (row lk + 4r, column lr) of the tile
-                const int i = i0 + li, j = j0 + lj;
-                if (i < n && j < n) {
-                    const double d = fmax(fma(-2.0, acc[ta][tb][r], na[li] + nb[lj]), 0.0);
-                    out[(int64_t)i * n + j] = exp(-d);
-                }
-            }
+        });
 }
 
 }  // namespace acoss
@@ -339,9 +304,16 @@ int acoss_ftm2d_pairs(const double *shingles, const int32_t *pairs, int K, doubl
 int acoss_ftm2d_gram(const double *shingles, int n, double *sims, void *stream)
 {
     if (!shingles || !sims || n < 1) { set_error("ftm2d_gram: bad argument"); return ACOSS_EINVAL; }
-    const unsigned t = (unsigned)ceil_div(n, FG_T);
-    hipLaunchKernelGGL(ftm2d_gram_kernel, dim3(t, t), dim3(256), 0, (hipStream_t)stream, shingles, n, sims);
-    return launch_check("ftm2d_gram_kernel");
+    hipStream_t st = (hipStream_t)stream;
+    double *norms = nullptr;
+    if (hipMalloc((void **)&norms, sizeof(double) * (size_t)n) != hipSuccess) { set_error("ftm2d_gram: device allocation failed"); return ACOSS_ENOMEM; }
+    hipLaunchKernelGGL(ftm2d_norms_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, shingles, n, norms);
+    const unsigned t = (unsigned)ceil_div(n, GM_T);
+    hipLaunchKernelGGL(ftm2d_gram_kernel, dim3(t, t), dim3(GM_THREADS), 0, st, shingles, norms, n, sims);
+    const int rc = launch_check("ftm2d_gram_kernel");
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(norms);
+    return rc;
 }
 
 }  // extern "C"

@@ -13,6 +13,7 @@
 //             ready for the kNN mask and alignment kernels.
 #include "common.h"
 #include "wave_ops.h"
+#include "gemm_f64.h"
 
 namespace acoss {
 
@@ -206,61 +207,22 @@ __global__ __launch_bounds__(256) void snf_mean_kernel(const double *const *__re
     out[e] = s / (double)n_src;
 }
 
-// C = X . Y^T per pair (all L x L, row-major): 64 x 64 block tiles, K in chunks of 32 through LDS, f64 MFMA
-typedef double v4f64_snf __attribute__((ext_vector_type(4)));
-constexpr int SG_T = 64, SG_KC = 32, SG_LD = SG_KC + 1;
-
-__global__ __launch_bounds__(256) void snf_gemm_nt_kernel(const double *__restrict__ X, const double *__restrict__ Y,
-                                                          const SnfPair *__restrict__ pairs, double *__restrict__ C)
+// C = X . Y^T per pair (all L x L, row-major): one 128 x 128 tile per block (gemm_f64.h)
+__global__ __launch_bounds__(GM_THREADS) void snf_gemm_nt_kernel(const double *__restrict__ X, const double *__restrict__ Y,
+                                                                 const SnfPair *__restrict__ pairs, double *__restrict__ C)
 {
-    __shared__ double Xs[SG_T][SG_LD], Ys[SG_T][SG_LD];
+    __shared__ GemmSmem sm;
     const SnfPair pr = pairs[blockIdx.z];
     const int L = pr.L;
-    const int i0 = blockIdx.y * SG_T, j0 = blockIdx.x * SG_T;
+    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
     if (i0 >= L || j0 >= L) return;
     const double *Xp = X + pr.w_off, *Yp = Y + pr.w_off;
-    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int lr = lane & 15, lk = lane >> 4;
-    const int wi = (wave >> 1) * 32, wj = (wave & 1) * 32;
-    v4f64_snf acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int b = 0; b < 2; b++) acc[a][b] = (v4f64_snf){0.0, 0.0, 0.0, 0.0};
-    for (int k0 = 0; k0 < L; k0 += SG_KC) {
-        for (int e = threadIdx.x; e < SG_T * SG_KC; e += 256) {
-            const int r = e / SG_KC, c = e % SG_KC;
-            const bool kin = k0 + c < L;
-            Xs[r][c] = (kin && i0 + r < L) ? Xp[(int64_t)(i0 + r) * L + k0 + c] : 0.0;
-            Ys[r][c] = (kin && j0 + r < L) ? Yp[(int64_t)(j0 + r) * L + k0 + c] : 0.0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int kk = 0; kk < SG_KC; kk += 4) {
-            double a[2], b[2];
-#pragma unroll
-            for (int t = 0; t < 2; t++) {
-                a[t] = Xs[wi + 16 * t + lr][kk + lk];
-                b[t] = Ys[wj + 16 * t + lr][kk + lk];
-            }
-#pragma unroll
-            for (int ta = 0; ta < 2; ta++)
-#pragma unroll
-                for (int tb = 0; tb < 2; tb++)
-                    acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
-        }
-        __syncthreads();
-    }
     double *Cp = C + pr.w_off;
-#pragma unroll
-    for (int ta = 0; ta < 2; ta++)
-#pragma unroll
-        for (int tb = 0; tb < 2; tb++)
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int i = i0 + wi + 16 * ta + lk + 4 * r, j = j0 + wj + 16 * tb + lr;
-                if (i < L && j < L) Cp[(int64_t)i * L + j] = acc[ta][tb][r];
-            }
+    gemm_nt_tile_f64(
+        sm, L,
+        [&](const int r, const int k) { return (i0 + r < L && k < L) ? Xp[(int64_t)(i0 + r) * L + k] : 0.0; },
+        [&](const int r, const int k) { return (j0 + r < L && k < L) ? Yp[(int64_t)(j0 + r) * L + k] : 0.0; },
+        [&](const int i, const int j, const double v) { if (i0 + i < L && j0 + j < L) Cp[(int64_t)(i0 + i) * L + j0 + j] = v; });
 }
 
 // -(mean_f P_f)[0:M, M:] into the pair's cross-recurrence layout (EarlySNF.py:84-85)
@@ -347,7 +309,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
     int rc = ACOSS_OK;
     if (hipMemcpyAsync(d_tab, tab, sizeof(SnfPair) * (size_t)K, hipMemcpyHostToDevice, st) != hipSuccess) rc = ACOSS_EIO;
     const dim3 g_el((unsigned)ceil_div(maxL, 256), (unsigned)maxL, (unsigned)K), g_row((unsigned)ceil_div(maxL, 4), (unsigned)K);
-    const dim3 g_mm((unsigned)ceil_div(maxL, SG_T), (unsigned)ceil_div(maxL, SG_T), (unsigned)K);
+    const dim3 g_mm((unsigned)ceil_div(maxL, GM_T), (unsigned)ceil_div(maxL, GM_T), (unsigned)K);
     for (int f = 0; f < n_feat && rc == ACOSS_OK; f++) {
         const SnfBlocks b{feats[f].ssma, feats[f].ssmb, feats[f].csm, feats[f].da, feats[f].db, feats[f].dc, feats[f].win};
         if (!b.ssma || !b.ssmb || !b.csm || !b.da || !b.db || !b.dc) { set_error("snf_cross_batch: feature %d has a null pointer", f); rc = ACOSS_EINVAL; break; }
@@ -378,9 +340,9 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                 hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n, tot, Xm);
                 src = Xm;
             }
-            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(256), 0, st, Sm[i], src, d_tab, Am);       // A = S . P^T   (:251)
+            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], src, d_tab, Am);       // A = S . P^T   (:251)
             double *dst = (it == 0) ? Pn[i] : Pm[i];
-            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(256), 0, st, Sm[i], Am, d_tab, dst);       // S . A^T       (:252)
+            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], Am, d_tab, dst);       // S . A^T       (:252)
             hipLaunchKernelGGL(snf_rowsum_kernel, g_row, dim3(256), 0, st, dst, d_tab, rowsum);
             hipLaunchKernelGGL(snf_reg_kernel, g_el, dim3(256), 0, st, dst, d_tab, rowsum, dst);          // :254-262
             rc = launch_check("snf diffusion kernels");

@@ -309,3 +309,28 @@ def test_wide_crp_selection_paths(eng, orc):
     q, d, _ = orc.serra09_pairs(corpus_h.feats, corpus_h.frame_off, corpus_h.gchroma, pairs, nthreads=4)
     assert np.array_equal(res["qmax"], q)
     assert np.array_equal(res["dmax"], d)
+
+
+def test_wide_feature_csm_on_matrix_cores(eng, orc):
+    """get_csm for float64 features wider than 32 (the scattering-feature case, Serra09.py:187): the MFMA kernel
+    against the oracle, with and without a roll, ragged sizes, d not a multiple of the k-chunk; and the m = 1 chain."""
+    rng = np.random.default_rng(12)
+    for d, shift in ((32, 0), (50, 7), (200, 0), (333, 41)):
+        X = np.cumsum(rng.standard_normal((70, d)), axis=0) * 0.1
+        Y = np.cumsum(rng.standard_normal((131, d)), axis=0) * 0.1
+        corpus = _pair_corpus(eng, X, Y)
+        batch = eng.PairBatch(corpus.frame_off, np.array([[0, 1]], dtype=np.int32), 1, corpus.device)
+        batch.set_shifts([shift])
+        C = eng.csm(corpus, batch).cpu().numpy()
+        dsc = batch.descs[0]
+        got = C[int(dsc["csm_off"]):int(dsc["csm_off"]) + 70 * int(dsc["csm_pitch"])].reshape(70, -1)[:, :131]
+        want = orc.get_csm(X, Y, shift)
+        assert np.max(np.abs(got - want)) <= 1e-9, (d, shift)
+    # the Serra09 chain without window on wide features (ssms_scatter_* scores)
+    A = np.cumsum(rng.standard_normal((90, 64)), axis=0) * 0.1
+    B = np.cumsum(rng.standard_normal((75, 64)), axis=0) * 0.1
+    corpus = _pair_corpus(eng, A, B)
+    res = eng.serra09_scores(corpus, np.array([[0, 1], [1, 0]], dtype=np.int32), m=1, do_oti=False)
+    for t, (x, y) in enumerate(((A, B), (B, A))):
+        q, dm = orc.serra09_pair(x, np.zeros(64), y, np.zeros(64), m=1, do_oti=False)
+        assert res["qmax"][t] == q and res["dmax"][t] == dm
