@@ -105,6 +105,34 @@ class Runner(object):
             self.side = torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
+        # The strip kernel's time depends on which allocation it writes (3.9 vs 4.4 ms for two
+        # 16 GB buffers in one process, any offset inside either gives the same time).  Try a few placements for
+        # the big intermediate once, before anything is timed, and keep the fastest.
+        self.placement_ms = None
+        if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
+            b0 = batches[0]
+            engine.oti(corpus, b0)
+            engine.pack_x(corpus, b0, out=self.xp)
+            cands, times = [self.S], []
+            try:
+                for _ in range(2):
+                    cands.append(torch.empty(tr + 32, dtype=torch.float64, device=dev))
+            except RuntimeError:
+                pass
+            for buf in cands:
+                planes = buf[:engine.planar_elems(b0)].view(torch.int32)
+                best = 1e9
+                for rep in range(3):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); engine.crp_planar(corpus, b0, self.xp, out=planes); e1.record()
+                    torch.cuda.synchronize()
+                    if rep:
+                        best = min(best, e0.elapsed_time(e1))
+                times.append(best)
+            self.S = cands[int(np.argmin(times))]
+            self.placement_ms = [round(t, 3) for t in times]
+            del cands
+            torch.cuda.empty_cache()
         self.plans = []
         for b in batches:
             mats, _ = b.mats()
@@ -274,6 +302,7 @@ def main():
                                "m=9 kappa=0.095 OTI, %d pairs/step/GPU of the %d-pair job"
                                % (args.songs, args.frames, P, len(all_pairs)),
                    "path": args.path, "pairs_per_step_per_gpu": P, "overlap_alignment_stream": bool(runner.overlap),
+                   "output_placement_probe_ms": runner.placement_ms,
                    "parallelism": "pair-shard x%d, one all-gather" % world},
         "roofline": {"kernel": kname, "bound": "hbm",
                      "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
