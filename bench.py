@@ -214,10 +214,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and rank == 0:
         print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    # one rank per GPU over RCCL (backend "nccl").  ACOSS_BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with
+    # fewer GPUs than ranks: ranks share the visible devices and the gather goes through host memory.
+    backend = os.environ.get("ACOSS_BENCH_DIST_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     m, kappa = 9, 0.095
     corpus_h = synth.config2(n_songs=args.songs, n_frames=args.frames)
@@ -251,8 +259,9 @@ def main():
     timed_idx = np.concatenate(step_idx[args.warmup:])
     local = scores[args.warmup:].reshape(-1)
     if world > 1:
-        gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered, local)
+        src = local if backend == "nccl" else local.cpu()
+        gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=src.device)
+        dist.all_gather_into_tensor(gathered, src)
     else:
         gathered = local
     host_scores = gathered.cpu().numpy()          # D2H of the results is inside the timed region
