@@ -41,7 +41,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--pairs-per-step", type=int, default=2048)
+    ap.add_argument("--pairs-per-step", type=int, default=4096,
+                    help="pairs per launch batch and GPU (4096 x 7.9 MB of windowed sums = 33 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--path", choices=("fast", "fast_f64", "staged"), default="fast",
@@ -293,10 +294,11 @@ def main():
     traffic, traffic_src = None, None
     pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_planar_pmc.json")
     pmc_key = {"fast": "crp_strip_kernel<12, 9, false, 0, false, true>"}.get(args.path)
-    if pmc_key and runner.planar and P == 2048 and args.frames == 1000 and os.path.exists(pmc_file):
+    if pmc_key and runner.planar and args.frames == 1000 and os.path.exists(pmc_file):
         with open(pmc_file) as fh:
-            c = json.load(fh).get(pmc_key)
-        if c and "hbm_write_GB" in c:
+            doc = json.load(fh)
+        c = doc.get(pmc_key)
+        if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
             traffic = round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9)
             traffic_src = "profiles/r01_planar_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
     if runner.planar:
