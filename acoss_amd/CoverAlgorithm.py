@@ -223,22 +223,28 @@ class CoverAlgorithm(object):
         One wsub x wsub sub-block of block `idx` of the lower-triangular w x w block grid, pairs
         with row >= col, the diagonal included (CoverAlgorithm.py:203-247).
         """
-        N = len(self.filepaths)
-        res = int(N / w)
-        I, J = np.meshgrid(np.arange(res), np.arange(res))
-        I, J = I.flatten(), J.flatten()
-        I, J = I[I >= J], J[I >= J]
-        i, j = I[idx], J[idx]
-        pixi = np.arange(w)[isub * wsub:(isub + 1) * wsub]
-        pixj = np.arange(w)[jsub * wsub:(jsub + 1) * wsub]
-        I, J = np.meshgrid(pixi, pixj)
-        idxs = np.array([I.flatten() + i * w, J.flatten() + j * w]).T
-        idxs = idxs[idxs[:, 0] < N, :]
-        idxs = idxs[idxs[:, 1] < N, :]
-        idxs = idxs[idxs[:, 0] >= idxs[:, 1], :]
-        similarities = self.similarity(idxs)
-        similarities['idxs'] = idxs
-        return similarities
+        idxs = self.subbatch_pairs(len(self.filepaths), w, idx, wsub, isub, jsub)
+        out = self.similarity(idxs)
+        out['idxs'] = idxs
+        return out
+
+    @staticmethod
+    def subbatch_pairs(n_songs, w, idx, wsub, isub, jsub):
+        """The (row, col) song pairs of one sub-block, in the reference's enumeration order.  Blocks of the
+        floor(n_songs / w)-wide block grid with block-row >= block-col are numbered column-major-within-row as
+        the reference's meshgrid/flatten does (:208-212): block number idx sits at block-column c, block-row r
+        where the numbering runs c = 0 (r = 0), c = 0..1 (r = 1) ... read along each grid row of the (J, I) mesh."""
+        nb = n_songs // w
+        # position idx in the sequence {(I, J) : meshgrid order, I >= J}: the mesh is indexed [a][b] with I = b, J = a
+        order = [(b, a) for a in range(nb) for b in range(nb) if b >= a]
+        bi, bj = order[idx]
+        rows = np.arange(isub * wsub, min((isub + 1) * wsub, w)) + bi * w
+        cols = np.arange(jsub * wsub, min((jsub + 1) * wsub, w)) + bj * w
+        # the reference flattens meshgrid(pixi, pixj): the first index varies fastest inside each value of the second
+        rr = np.tile(rows, len(cols))
+        cc = np.repeat(cols, len(rows))
+        keep = (rr < n_songs) & (cc < n_songs) & (rr >= cc)
+        return np.stack([rr[keep], cc[keep]], axis=1)
 
     def do_batch(self, w, idx, wsub=-1):
         """

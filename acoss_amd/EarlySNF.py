@@ -10,7 +10,6 @@ SSM-scatter features (without), 3 cross-diffusion iterations (SimilarityFusion.s
 qmax / dmax on the negated cross block of the fused matrix.  As in the reference, MFCC stays out of the fusion (:64).
 Songs need the precomputed 'ssms' features (the scattering transform itself is outside the accelerated path).
 """
-import argparse
 
 import numpy as np
 
@@ -68,18 +67,6 @@ class EarlySNF(Serra09):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(description="Benchmarking with early fusion + QMax/DMax (MI355X path)",
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("-d", '--datapath', type=str, action="store", default='../features_covers80', help="Path to data files")
-    parser.add_argument("-s", "--shortname", type=str, action="store", default="covers80", help="Short name for dataset")
-    parser.add_argument("-c", '--chroma_type', type=str, action="store", default='crema', help="Type of chroma to use for experiments")
-    parser.add_argument("-p", '--parallel', type=int, choices=(0, 1), action="store", default=0, help="Accepted for compatibility")
-    parser.add_argument("-n", '--n_cores', type=int, action="store", default=1, help="Accepted for compatibility")
-    cmd_args = parser.parse_args()
-    snf = EarlySNF(cmd_args.datapath, cmd_args.chroma_type, cmd_args.shortname)
-    snf.all_pairwise(cmd_args.parallel, cmd_args.n_cores, symmetric=True)
-    for similarity_type in snf.Ds.keys():
-        print(similarity_type)
-        snf.getEvalStatistics(similarity_type)
-    snf.cleanup_memmap()
-    print("... Done ....")
+    from ._cli import run
+    run(lambda a, mm: EarlySNF(a.datapath, a.chroma_type, a.shortname, do_memmaps=mm),
+        "Benchmarking with early fusion + QMax/DMax", "crema", "covers80")

@@ -10,7 +10,6 @@ Host side, per song: the beat synchronisation (librosa.util.sync with the madmom
 not available here; `sync_median` restates its documented behaviour (median over the frames between consecutive
 boundaries of {0} U onsets U {n}).
 """
-import argparse
 
 import numpy as np
 
@@ -113,19 +112,6 @@ class FTM2D(CoverAlgorithm):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(description="Benchmarking with 2D Fourier Transform Magnitude Coefficients (MI355X path)",
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("-d", '--datapath', type=str, action="store", default='../features_covers80', help="Path to data files")
-    parser.add_argument("-s", "--shortname", type=str, action="store", default="Covers80", help="Short name for dataset")
-    parser.add_argument("-c", '--chroma_type', type=str, action="store", default='hpcp', help="Type of chroma to use for experiments")
-    parser.add_argument("-p", '--parallel', type=int, choices=(0, 1), action="store", default=0, help="Accepted for compatibility")
-    parser.add_argument("-n", '--n_cores', type=int, action="store", default=1, help="Accepted for compatibility")
-    cmd_args = parser.parse_args()
-    ftm2d = FTM2D(cmd_args.datapath, cmd_args.chroma_type, cmd_args.shortname)
-    ftm2d.compute_all_shingles()
-    print('Feature loading done.')
-    ftm2d.all_pairwise(cmd_args.parallel, cmd_args.n_cores, symmetric=True)
-    for similarity_type in ftm2d.Ds.keys():
-        ftm2d.getEvalStatistics(similarity_type)
-    ftm2d.cleanup_memmap()
-    print("... Done ....")
+    from ._cli import run
+    run(lambda a, mm: FTM2D(a.datapath, a.chroma_type, a.shortname, do_memmaps=mm),
+        "Benchmarking with 2D Fourier Transform Magnitude Coefficients", "hpcp", "Covers80")

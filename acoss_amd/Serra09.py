@@ -15,7 +15,6 @@ MFCC (global chroma on the full-resolution chroma, median / mean aggregation ove
 features (kymatio, skimage) are outside the hot path's scope: songs that carry a precomputed
 'ssms' array get ssms_scatter_* scores, others get zeros for those two keys.
 """
-import argparse
 import warnings
 
 import numpy as np
@@ -165,38 +164,6 @@ class Serra09(CoverAlgorithm):
 
 
 if __name__ == '__main__':
-    parser = argparse.ArgumentParser(description="Benchmarking with Joan Serra's Cover id algorithm (MI355X path)",
-                                     formatter_class=argparse.ArgumentDefaultsHelpFormatter)
-    parser.add_argument("-d", '--datapath', type=str, action="store", default='../features_covers80',
-                        help="Path to data files")
-    parser.add_argument("-s", "--shortname", type=str, action="store", default="covers80", help="Short name for dataset")
-    parser.add_argument("-c", '--chroma_type', type=str, action="store", default='crema',
-                        help="Type of chroma to use for experiments")
-    parser.add_argument("-p", '--parallel', type=int, choices=(0, 1), action="store", default=0,
-                        help="Accepted for compatibility; the GPU batch is the parallelism")
-    parser.add_argument("-n", '--n_cores', type=int, action="store", default=1, help="Accepted for compatibility")
-    parser.add_argument("-r", "--range", type=str, action="store", default="")
-    parser.add_argument("-f", "--features", type=int, choices=(0, 1), action="store", default=0, help="Compute features only")
-    parser.add_argument("-w", "--wsub", type=int, action="store", default=-1, help="Size of subbatch block")
-    parser.add_argument("-b", "--batch_path", type=str, action="store", default="")
-    cmd_args = parser.parse_args()
-
-    do_memmaps = len(cmd_args.range) == 0
-    serra09 = Serra09(cmd_args.datapath, cmd_args.chroma_type, cmd_args.shortname, do_memmaps=do_memmaps)
-    if len(cmd_args.batch_path) > 0:
-        serra09.load_batches(cmd_args.batch_path)
-        for similarity_type in serra09.Ds.keys():
-            serra09.getEvalStatistics(similarity_type)
-    elif do_memmaps:
-        serra09.all_pairwise(cmd_args.parallel, cmd_args.n_cores, symmetric=True)
-        for similarity_type in serra09.Ds.keys():
-            print(similarity_type)
-            serra09.getEvalStatistics(similarity_type)
-        serra09.cleanup_memmap()
-    else:
-        [w, idx] = [int(s) for s in cmd_args.range.split("-")]
-        if cmd_args.features == 1:
-            serra09.do_batch_features(w, idx)
-        else:
-            serra09.do_batch(w, idx, cmd_args.wsub)
-    print("... Done ....")
+    from ._cli import run
+    run(lambda a, mm: Serra09(a.datapath, a.chroma_type, a.shortname, do_memmaps=mm),
+        "Benchmarking with Joan Serra's Cover id algorithm", "crema", "covers80", batch_options=True)
