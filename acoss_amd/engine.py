@@ -379,8 +379,18 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     out = {k: np.zeros(K) for k in want}
     if K == 0:
         return out
+    # pairs whose matrices fit the bit-mask kernels (<= 1024 x 1024) and the few that do not go through separate
+    # batches, so that one long song does not push a whole batch onto the byte-mask path
+    lens = corpus.lengths()
+    big = np.maximum(lens[pairs[:, 0]], lens[pairs[:, 1]]) - m + 1 > 1024
+    if big.any() and not big.all() and "swc" not in want:
+        for part in (np.flatnonzero(~big), np.flatnonzero(big)):
+            res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs)
+            for k in want:
+                out[k][part] = res[k]
+        return out
     if batch_pairs is None:
-        per_pair = float(corpus.lengths().max()) ** 2 * 9.2
+        per_pair = float(max(lens[pairs[:, 0]].max(), lens[pairs[:, 1]].max())) ** 2 * 9.2
         batch_pairs = int(max(1, min(K, (8 << 30) // max(per_pair, 1.0))))
     xp = T = B = work = None
     for lo in range(0, K, batch_pairs):

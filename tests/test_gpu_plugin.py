@@ -116,3 +116,18 @@ def test_config3_shape_smith_waterman_chain(orc):
         sw = orc.swconstrained(Bf, np.zeros((M + 1) * (N + 1), dtype=np.float32), M, N) / (M + N)
         assert got["qmax"][t] == q and got["dmax"][t] == d, (t, i, j)
         assert abs(got["swc"][t] - sw) <= 1e-5, (t, i, j, got["swc"][t], sw)
+
+
+def test_mixed_size_batch_splits_by_size_class(orc):
+    """A pair list mixing <= 1032-frame songs (bit-mask path) with longer ones (byte-mask path): same scores as the
+    oracle, in the caller's order."""
+    from acoss_amd import engine, synth
+    engine.require_gpu()
+    lens_it = iter([300, 1100, 420, 1050, 200])
+    ch = synth.make_corpus(5, 1, seed=7, lengths=lambda r: next(lens_it))
+    pairs = np.array([(0, 2), (1, 0), (2, 4), (3, 1), (4, 0), (2, 3)], dtype=np.int32)
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    got = engine.serra09_scores(corpus, pairs)
+    for t, (i, j) in enumerate(pairs):
+        q, d = orc.serra09_pair(ch.song(i), ch.gchroma[i], ch.song(j), ch.gchroma[j])
+        assert got["qmax"][t] == q and got["dmax"][t] == d, (t, i, j)
