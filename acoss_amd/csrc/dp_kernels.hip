@@ -524,9 +524,10 @@ __global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restri
 template <int KIND>
 __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict__ bits,
                                                       const acoss_pair_desc *__restrict__ descs, int K, int win,
-                                                      int max_m, float gamma, int boundary,
+                                                      int max_m, float gamma, int boundary, float4 sw,
                                                       float *__restrict__ scores)
 {
+    // sw = (match, mismatch, gap open, gap extension) of swalignimpconstrained (SequenceAlignment.c:43-63)
     constexpr int CPL = 16;
     constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
     constexpr int R0 = (KIND == KIND_DMAX) ? 1 : 2;
@@ -564,6 +565,11 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
                 h0 = (unsigned)lane_shr1((int)m0, 0);
             }
             const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);
+            unsigned ext1 = 0, ext2 = 0;            // rows i-1, i-2 shifted so that bit c+2 = column c (KIND_SWC)
+            if (KIND == KIND_SWC) {
+                ext1 = (m1 << 2) | (((unsigned)lane_shr1((int)m1, 0) >> 14) & 3u);
+                ext2 = (m2 << 2) | (((unsigned)lane_shr1((int)m2, 0) >> 14) & 3u);
+            }
             float nd[CPL];
 #pragma unroll
             for (int c = 0; c < CPL; c++) {
@@ -586,6 +592,14 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
                 }
                 const bool on = (m0 >> c) & 1u;
                 float v = fmaxf(m + (on ? 1.0f : -gamma), 0.0f);
+                if (KIND == KIND_SWC) {
+                    // same expression order as dp_wave_kernel<KIND_SWC> (the -0.7 penalty is inexact in float32)
+                    const float ms = on ? sw.x : sw.y;
+                    const float e1 = on ? 0.0f : (((ext1 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-1][b-1]
+                    const float e2 = on ? 0.0f : (((ext2 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-2][b-1]
+                    const float e3 = on ? 0.0f : (((ext1 >> c) & 1u) ? sw.z : sw.w);           // S[a-1][b-2]
+                    v = fmaxf(max3f((p_diag + ms) + e1, (p_up2 + ms) + e2, (p_left2 + ms) + e3), 0.0f);
+                }
                 if (c < FIRST) {
                     const float bval = (KIND == KIND_DMAX && c == 2 && boundary) ? (float)((m0 >> 2) & 1u) : 0.0f;
                     best = fmaxf(best, l0 ? 0.0f : v);
@@ -672,8 +686,8 @@ int acoss_swc_batch(const uint8_t *S, const acoss_mat_desc *mats, int K, int max
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win, int max_nx,
                            int max_ny, int boundary, const acoss_align_params *params, float *scores, void *stream)
 {
-    if (!bits || !descs || !scores || K < 0 || win < 1 || max_nx < win || max_ny < win || (kind != 0 && kind != 1)) {
-        set_error("align_bits_batch: bad argument (kind 0 = qmax, 1 = dmax)");
+    if (!bits || !descs || !scores || K < 0 || win < 1 || max_nx < win || max_ny < win || kind < 0 || kind > 2) {
+        set_error("align_bits_batch: bad argument (kind 0 = qmax, 1 = dmax, 2 = swalignimpconstrained)");
         return ACOSS_EINVAL;
     }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
@@ -685,10 +699,13 @@ int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc
     }
     if (K == 0) return ACOSS_OK;
     hipStream_t st = (hipStream_t)stream;
+    const float4 sw = make_float4(ap.sw_match, ap.sw_mismatch, ap.sw_gap_open, ap.sw_gap_ext);
     if (kind == 0)
-        hipLaunchKernelGGL(dp_bits_kernel<KIND_QMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, scores);
+        hipLaunchKernelGGL(dp_bits_kernel<KIND_QMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+    else if (kind == 1)
+        hipLaunchKernelGGL(dp_bits_kernel<KIND_DMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, sw, scores);
     else
-        hipLaunchKernelGGL(dp_bits_kernel<KIND_DMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, scores);
+        hipLaunchKernelGGL(dp_bits_kernel<KIND_SWC>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
     return launch_check("dp_bits_kernel");
 }
 

@@ -306,12 +306,12 @@ def mask_bits_planar(planes, batch, kappa, mutual=True, out=None, work=None):
 
 
 def align_bits(kind, bits, batch, boundary=0, params=None, scores=None):
-    """qmax / dmax from the bit-packed mask."""
+    """qmax / dmax / swalignimpconstrained from the bit-packed mask."""
     lib = _lib.load()
     if scores is None:
         scores = torch.empty(max(batch.K, 1), dtype=torch.float32, device=bits.device)
     pp = ctypes.byref(params) if params is not None else None
-    check(lib.acoss_align_bits_batch({"qmax": 0, "dmax": 1}[kind], _ptr(bits), _ptr(batch.descs_dev), batch.K,
+    check(lib.acoss_align_bits_batch({"qmax": 0, "dmax": 1, "swc": 2}[kind], _ptr(bits), _ptr(batch.descs_dev), batch.K,
                                      batch.win, batch.max_nx, batch.max_ny, int(boundary), pp, _ptr(scores),
                                      _stream()), "align_bits_batch")
     return scores[:batch.K]
@@ -383,7 +383,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     # batches, so that one long song does not push a whole batch onto the byte-mask path
     lens = corpus.lengths()
     big = np.maximum(lens[pairs[:, 0]], lens[pairs[:, 1]]) - m + 1 > 1024
-    if big.any() and not big.all() and "swc" not in want:
+    if big.any() and not big.all():
         for part in (np.flatnonzero(~big), np.flatnonzero(big)):
             res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs)
             for k in want:
@@ -403,9 +403,8 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
             T = torch.empty(planar_elems(batch), dtype=torch.float64, device=corpus.device)
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
         denom = (batch.M + batch.N).astype(np.float64)
-        if "swc" in want:
-            # Smith-Waterman with the -0.5 / -0.7 gap penalties (SequenceAlignment.c:73-99) reads neighbouring mask
-            # bytes in its Delta terms: byte mask + dp_wave_kernel<swc>; the bit-mask kernels cover qmax / dmax
+        if "swc" in want and not (planar_supported(corpus, batch) or bits_path_supported(batch)):
+            # matrices beyond 1024 x 1024: byte mask + dp_wave_kernel / dp_block_kernel
             crp(corpus, batch, xp, sqrt_out=False, out=T)
             binarize(T, batch, kappa, mutual=True, out=B, work=work)
             mats, _ = batch.mats()
@@ -426,6 +425,8 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                 out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
             if "dmax" in want:
                 out["dmax"][lo:lo + len(sel)] = align_bits("dmax", bits, batch, boundary=1).cpu().numpy().astype(np.float64) / denom
+            if "swc" in want:
+                out["swc"][lo:lo + len(sel)] = align_bits("swc", bits, batch).cpu().numpy().astype(np.float64) / denom
             continue
         if fused_align_supported(batch):
             work = thresholds(T, batch, kappa, mutual=True, work=work)

@@ -233,7 +233,7 @@ int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *de
  * bit c = column 64w + c; bits past the row end are zero).  The selection kernels emit each row's and each
  * column's selected positions as bit vectors by ballot; a tile kernel transposes the column vectors and ANDs.
  * `work` needs acoss_mask_bits_work_bytes() bytes (thresholds + the two bit planes).
- * acoss_align_bits_batch runs qmax (kind 0) / dmax (kind 1) from those bits, one wave per pair
+ * acoss_align_bits_batch runs qmax (kind 0) / dmax (kind 1) / swalignimpconstrained (kind 2) from those bits, one wave per pair
  * (gamma_onset == gamma_extension required; `boundary` as for acoss_dmax_batch). */
 size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win);
 int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,

@@ -253,3 +253,26 @@ def test_planar_mask_equals_float64_mask(eng, golden):
             want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
             got, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=mutual)
             assert torch.equal(got, want), mutual
+
+
+def test_smith_waterman_from_bits_equals_from_bytes(eng, golden):
+    """swalignimpconstrained from the bit mask == from the byte mask (same float32 expression order), mutual and
+    one-sided masks, ragged sizes."""
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"]),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32))]
+    for feats, off, gc, pairs in cases:
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device)
+        eng.oti(corpus, batch)
+        T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+        mats, _ = batch.mats()
+        for mutual in (True, False):
+            B = eng.binarize(T, batch, 0.095, mutual=mutual)
+            bits, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+            a = eng.align_bits("swc", bits, batch).cpu().numpy()
+            b = eng.align("swc", B, mats).cpu().numpy()
+            assert np.array_equal(a, b), mutual
