@@ -77,7 +77,7 @@ class Runner(object):
         # fast path: the alignment sweep (latency-bound: 992 serial row steps, ~15 % VALU) of batch b runs
         # on a second HIP stream while the main stream already computes batch b+1 (two sets of T/threshold
         # buffers, events both ways)
-        self.overlap = overlap and path == "fast_f64"
+        self.overlap = False
         # "fast": T leaves the strip kernel as two uint32 planes (key high / low words) and the selections read
         # only the high-word plane; "fast_f64": T as float64, selections read 8 bytes per element
         self.planar = path == "fast" and all(engine.planar_supported(corpus, b) for b in batches)
@@ -100,9 +100,12 @@ class Runner(object):
         else:
             need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
         self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        # --overlap: the alignment sweep (latency-bound: 992 serial row steps, one wave per pair, 124 KB of mask per
+        # pair) of batch b runs on a second HIP stream while the main stream already builds batch b + 1 (two mask
+        # buffers, events both ways)
+        self.overlap = bool(overlap) and self.planar
         if self.overlap:
-            self.Ss = [self.S, torch.empty(tr, dtype=torch.float64, device=dev)]
-            self.works = [self.work, torch.empty(need, dtype=torch.uint8, device=dev)]
+            self.bits2 = [self.bits, torch.zeros_like(self.bits)]
             self.side = torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
@@ -156,21 +159,21 @@ class Runner(object):
             torch = self.torch
             slot = i & 1
             main = torch.cuda.current_stream()
-            main.wait_event(self.free[slot])          # the sweep that last read this slot has finished
-            S, work = self.Ss[slot], self.works[slot]
+            main.wait_event(self.free[slot])          # the sweep that last read this mask buffer has finished
             mark(0)
             e.oti(self.corpus, b)
             mark(1)
             e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            e.crp(self.corpus, b, self.xp, sqrt_out=False, out=S)
+            planes = self.S[:e.planar_elems(b)].view(torch.int32)
+            e.crp_planar(self.corpus, b, self.xp, out=planes)
             mark(3)
-            e.thresholds(S, b, self.kappa, True, work=work)
+            e.mask_bits_planar(planes, b, self.kappa, True, out=self.bits2[slot], work=self.work)
+            mark(4)
             self.ready[slot].record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ready[slot])
-                mark(4)
-                e.align_fused("qmax", S, b, work, scores=scores_out)   # the register-heavy sweep straight from T
+                e.align_bits("qmax", self.bits2[slot], b, scores=scores_out)
                 mark(5)
                 self.free[slot].record(self.side)
             return

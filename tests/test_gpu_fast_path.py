@@ -276,3 +276,37 @@ def test_smith_waterman_from_bits_equals_from_bytes(eng, golden):
             a = eng.align_bits("swc", bits, batch).cpu().numpy()
             b = eng.align("swc", B, mats).cpu().numpy()
             assert np.array_equal(a, b), mutual
+
+
+def test_full_size_properties(eng, orc):
+    """BASELINE config 2 shape (1000-frame songs, 992 x 992 cross-recurrence plots, k = 94) through properties that do not
+    need a full oracle run: exactly k ones per row / column of the one-sided masks, mutual = AND of the two, scores on
+    the 0.5 grid, transpose symmetry without OTI, fast path == staged path, and the oracle on a few pairs."""
+    from acoss_amd import synth
+    ch = synth.make_corpus(6, 2, n_frames=1000, seed=20260)
+    corpus = eng.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = synth.all_pairs(ch.n_songs)[:48]
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    xp = eng.pack_x(corpus, batch)                       # no OTI: shifts stay 0
+    planes = eng.crp_planar(corpus, batch, xp)
+    rows_only, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=False)
+    mutual, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=True)
+    swapped = eng.PairBatch(corpus.frame_off, pairs[:, ::-1].copy(), 9, corpus.device, pitch_align=32)
+    planes_t = eng.crp_planar(corpus, swapped, eng.pack_x(corpus, swapped))
+    cols_only_t, _ = eng.mask_bits_planar(planes_t, swapped, 0.095, mutual=False)       # rows of the transposed pair = columns
+    for p in range(0, 48, 5):
+        R = eng.unpack_mask_bits(rows_only, batch, p)
+        Ct = eng.unpack_mask_bits(cols_only_t, swapped, p)
+        Mu = eng.unpack_mask_bits(mutual, batch, p)
+        assert R.shape == (992, 992) and np.all(R.sum(1) == 94) and np.all(Ct.sum(1) == 94)
+        assert np.array_equal(Mu, R & Ct.T)
+    q = eng.align_bits("qmax", mutual, batch).cpu().numpy()
+    d = eng.align_bits("dmax", mutual, batch, boundary=1).cpu().numpy()
+    assert np.all(q * 2 == np.round(q * 2)) and np.all(d * 2 == np.round(d * 2)) and np.all(d >= q)
+    mutual_t, _ = eng.mask_bits_planar(planes_t, swapped, 0.095, mutual=True)
+    assert np.array_equal(eng.align_bits("qmax", mutual_t, swapped).cpu().numpy(), q)
+    fast = eng.serra09_scores(corpus, pairs, do_oti=True)
+    staged = eng.serra09_scores_staged(corpus, pairs, do_oti=True)
+    assert np.array_equal(fast["qmax"], staged["qmax"]) and np.array_equal(fast["dmax"], staged["dmax"])
+    oq, od, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs[:6], nthreads=6)
+    assert np.array_equal(fast["qmax"][:6], oq) and np.array_equal(fast["dmax"][:6], od)
