@@ -370,6 +370,34 @@ def main():
                                "sample": "%d pairs of the same workload through oracle/acoss_oracle.c "
                                          "(OpenMP over pairs, %.1f s)" % (n_cpu, cpu_s)}
         out["parity"] = {"checked_pairs": int(n_cpu), "identical": bool(np.array_equal(gpu_q, q_cpu))}
+        # beside it: the reference's own SequenceAlignment.c (compiled in place by oracle/Makefile into oracle/_ref,
+        # -Ofast as in its setup.py) on the alignment step alone -- qmax_c over the same masks, one call per pair,
+        # spread over the host threads (ctypes releases the GIL)
+        ref = oracle.ref_lib("Ofast")
+        if ref is not None:
+            from concurrent.futures import ThreadPoolExecutor
+            n_dp = min(8 * threads, n_cpu)
+            masks = []
+            for i, j in sample[:n_dp]:
+                X, Y = corpus_h.song(int(i)), corpus_h.song(int(j))
+                S = oracle.sliding_csm(oracle.get_csm(X, Y, oracle.get_oti(corpus_h.gchroma[i], corpus_h.gchroma[j])), m)
+                masks.append(np.ascontiguousarray(oracle.csm_to_binary_mutual(S, kappa).flatten()))
+            Mn = args.frames - m + 1
+
+            def one(Bf):
+                D = np.zeros(Mn * Mn, dtype=np.float32)
+                return float(ref.qmax_c(oracle._u(Bf), oracle._f(D), Mn, Mn))
+            reps = 4
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(threads) as ex:
+                for _ in range(reps):
+                    q_ref = list(ex.map(one, masks))
+            dp_s = time.perf_counter() - t0
+            out["cpu_baseline_alignment_only"] = {
+                "value": round(reps * n_dp / dp_s, 1), "unit": "qmax_c calls/s", "cores": threads, "kind": "reference",
+                "sample": "%d x %d calls of the reference's qmax_c (SequenceAlignment.c:113, -Ofast) on %dx%d masks, D zeroed per "
+                          "call" % (reps, n_dp, Mn, Mn),
+                "identical_to_gpu": bool(np.array_equal(np.array(q_ref) / denom, gpu_q[:n_dp]))}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
