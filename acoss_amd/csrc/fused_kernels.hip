@@ -485,10 +485,32 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     // can put in its vmcnt waits, which keeps the x prefetch and the result stores in flight across
     // steps (with data-dependent store counts it falls back to vmcnt(0): a full HBM round trip per step).
     auto step = [&](const int t, auto checked_tag) {
+        // Everything that depends on the thread number is re-derived here from a laundered copy of it: kept live
+        // across the loop these per-thread constants (LDS pointers, column numbers, role flags) cost ~12 VGPRs,
+        // and the kernel needs <= 80 for a third block per CU; re-deriving them costs ~25 VALU per step.
+        int tid_ = threadIdx.x;
+        asm volatile("" : "+v"(tid_));
+        const int lane_ = tid_ & 63;
+        const int lr_ = lane_ & 15, lk_ = lane_ >> 4;
+        const bool loader_ = tid_ < STRIP_ROWS * (XP_STRIDE / 2);
+        double *xs_dst_ = &xs[(tid_ >> 3) * XS_LD + (tid_ & 7) * 2];
+        const int ca_ = lane_, cb_ = lane_ + 64;
+        const bool oka_ = ca_ < TN && j0 + ca_ < N, okb_ = cb_ < TN && j0 + cb_ < N;
+        const int cbr_ = okb_ ? cb_ : ca_;
+        const double *rda_ = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + ca_;
+        const double *rdb_ = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + cbr_;
+        double *wr_ = cbuf + (HALO + lk_) * CRP_LD + 16 * wave + lr_;
+        const int dcol_ = 2 * lane_ - ROWS_PER_WAVE;
+        const double *rdd_ = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + dcol_;
+        const bool copier_ = tid_ < HALO * (CRP_CT / 2);
+        const int hrow_ = (2 * tid_) / CRP_CT, hcol_ = (2 * tid_) % CRP_CT;
+        double *halo_src_ = cbuf + ((copier_ ? STRIP_ROWS + hrow_ : 0)) * CRP_LD + hcol_;
+        double *halo_dst_ = cbuf + (copier_ ? hrow_ : 0) * CRP_LD + hcol_;
+        (void)rda_; (void)rdb_; (void)rdd_; (void)oka_; (void)okb_; (void)cb_;
         constexpr bool CHECKED = decltype(checked_tag)::value;
         const bool more = t + 1 < n_steps;
-        if (loader && t + 2 < n_steps)
-            xn2 = reinterpret_cast<const double2 *>(xsrc)[min((t + 2) * STRIP_ROWS * (XP_STRIDE / 2) + (int)threadIdx.x, last_chunk)];
+        if (loader_ && t + 2 < n_steps)
+            xn2 = reinterpret_cast<const double2 *>(xsrc)[min((t + 2) * STRIP_ROWS * (XP_STRIDE / 2) + tid_, last_chunk)];
         // ---- C rows [32t, 32t+32) of this wave's 16 columns -> cbuf rows [HALO, HALO+32)
         if (MODE != 3) {
             v4f64 acc[2];
@@ -498,7 +520,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
             for (int s = 0; s < KSTEPS; s++) {
 #pragma unroll
                 for (int rb = 0; rb < 2; rb++) {
-                    const double a = xs[(16 * rb + lr) * XS_LD + 4 * s + lk];
+                    const double a = xs[(16 * rb + lr_) * XS_LD + 4 * s + lk_];
                     acc[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bfrag[s], acc[rb], 0, 0, 0);
                 }
             }
@@ -506,28 +528,28 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
             for (int rb = 0; rb < 2; rb++) {
 #pragma unroll
                 for (int r = 0; r < 4; r++) {
-                    const double c = fma(-2.0, acc[rb][r], xs[(16 * rb + lk + 4 * r) * XS_LD + D] + yy);
-                    wr[(16 * rb + 4 * r) * CRP_LD] = fmax(c, 0.0);
+                    const double c = fma(-2.0, acc[rb][r], xs[(16 * rb + lk_ + 4 * r) * XS_LD + D] + yy);
+                    wr_[(16 * rb + 4 * r) * CRP_LD] = fmax(c, 0.0);
                 }
             }
         }
         lds_barrier();
         // next step's x frames may now replace the current ones (nobody reads xs until the next step)
-        if (loader && more) *reinterpret_cast<double2 *>(xs_dst) = xn1;
+        if (loader_ && more) *reinterpret_cast<double2 *>(xs_dst_) = xn1;
         xn1 = xn2;
         // ---- output rows [32t - HALO, 32t + 32 - HALO): ROWS_PER_WAVE per wave, window sums from LDS
         const int g0 = t * STRIP_ROWS - HALO + wave * ROWS_PER_WAVE;          // wave-uniform
         if constexpr (DIAG) {
-            // Output (q, c) and (q + 1, c + 1) share WIN - 1 of their WIN addends, so a lane walks two adjacent
+            // Output (q, c) and (q + 1, c + 1) share WIN - 1 of their WIN addends, so a lane_ walks two adjacent
             // diagonals for ROWS_PER_WAVE rows: ROWS_PER_WAVE + WIN - 1 two-element LDS reads instead of
             // 2 * ROWS_PER_WAVE * WIN single ones, each output still summed in the order k = 0..WIN-1.
-            // Row q of the wave then sits at columns dcol + q, dcol + q + 1: an aligned pair for even q; for
-            // odd q the pair is (own second diagonal, first diagonal of the next lane), one DPP shift.
+            // Row q of the wave then sits at columns dcol_ + q, dcol_ + q + 1: an aligned pair for even q; for
+            // odd q the pair is (own second diagonal, first diagonal of the next lane_), one DPP shift.
             double va[ROWS_PER_WAVE + HALO], vb[ROWS_PER_WAVE + HALO];
 #pragma unroll
             for (int m = 0; m < ROWS_PER_WAVE + HALO; m++) {
-                va[m] = rdd[m * (CRP_LD + 1)];
-                vb[m] = rdd[m * (CRP_LD + 1) + 1];
+                va[m] = rdd_[m * (CRP_LD + 1)];
+                vb[m] = rdd_[m * (CRP_LD + 1) + 1];
             }
 #pragma unroll
             for (int q = 0; q < ROWS_PER_WAVE; q++) {
@@ -547,7 +569,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     sa = csm_sqrt(sa);
                     sb = csm_sqrt(sb);
                 }
-                const int col = dcol + q;
+                const int col = dcol_ + q;
                 if constexpr (PLANAR) {
                     // row start = 32 A + pb (A, pb wave-uniform); strip column c sits u = pb + c values into block A:
                     // high word at byte 256 A + 4 (u + (u & ~31)), low word 128 bytes later
@@ -568,7 +590,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                             __builtin_amdgcn_raw_buffer_store_b32(lb, orsrc, hw(col + 1) + 128, soff, 0);
                         }
                     } else {
-                        // this lane's pair of the row: columns ps, ps + 1 (ps even)
+                        // this lane_'s pair of the row: columns ps, ps + 1 (ps even)
                         uint32_t h0 = ha, h1 = hb, l0 = la, l1 = lb;
                         int ps = col;
                         if ((q & 1) != 0) {
@@ -580,19 +602,19 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                         if (quad_ok) {
                             // two neighbouring lanes hold four adjacent columns: the one whose pair starts the
                             // aligned quad writes the four high words (16 bytes to plane 0), the other one the
-                            // four low words (plane 1) -- one 16-byte store per lane and row, as in the float64 form
-                            const int EQ = (q & 1) ? q - (ROWS_PER_WAVE - 1) : q - ROWS_PER_WAVE;      // ps = 2 * lane + EQ (constant after unrolling)
+                            // four low words (plane 1) -- one 16-byte store per lane_ and row, as in the float64 form
+                            const int EQ = (q & 1) ? q - (ROWS_PER_WAVE - 1) : q - ROWS_PER_WAVE;      // ps = 2 * lane_ + EQ (constant after unrolling)
                             uint32_t g0, g1;
                             bool leader;
                             if ((EQ & 3) == 0) {
-                                leader = (lane & 1) == 0;
+                                leader = (lane_ & 1) == 0;
                                 g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l0 : h0), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
                                 g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l1 : h1), 0xB1, 0xf, 0xf, true);
                             } else {
-                                leader = (lane & 1) != 0;
-                                const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x130, 0xf, 0xf, true);      // from lane + 1
+                                leader = (lane_ & 1) != 0;
+                                const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x130, 0xf, 0xf, true);      // from lane_ + 1
                                 const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0x130, 0xf, 0xf, true);
-                                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l0, 0x138, 0xf, 0xf, true);      // from lane - 1
+                                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l0, 0x138, 0xf, 0xf, true);      // from lane_ - 1
                                 const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l1, 0x138, 0xf, 0xf, true);
                                 g0 = leader ? a0 : b0;
                                 g1 = leader ? a1 : b1;
@@ -632,13 +654,13 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
             if (!CHECKED || (gi >= 0 && gi < M)) {
                 double sa = 0.0, sb = 0.0;
                 if (MODE == 2) {
-                    sa = rda[q * CRP_LD];
-                    sb = rdb[q * CRP_LD];
+                    sa = rda_[q * CRP_LD];
+                    sb = rdb_[q * CRP_LD];
                 } else {
 #pragma unroll
                     for (int k = 0; k < WIN; k++) {
-                        sa += rda[(q + k) * CRP_LD + k];
-                        sb += rdb[(q + k) * CRP_LD + k];
+                        sa += rda_[(q + k) * CRP_LD + k];
+                        sb += rdb_[(q + k) * CRP_LD + k];
                     }
                 }
                 if (SQRT_OUT) {
@@ -647,20 +669,20 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                 }
                 double *o = orow + (int64_t)(t * STRIP_ROWS + q) * o_pitch;
                 if (MODE == 1) {
-                    if (sa == -1.25) o[ca] = sb;
+                    if (sa == -1.25) o[ca_] = sb;
                 } else if (CHECKED) {
-                    if (oka) o[ca] = sa;
-                    if (okb) o[cb] = sb;
+                    if (oka_) o[ca_] = sa;
+                    if (okb_) o[cb_] = sb;
                 } else {
-                    // pair up adjacent columns across neighbouring lanes (one DPP swap) so that every lane
+                    // pair up adjacent columns across neighbouring lanes (one DPP swap) so that every lane_
                     // issues ONE 16-byte store: even lanes write columns (l, l+1), odd lanes (63+l, 64+l)
-                    const bool odd = lane & 1;
+                    const bool odd = lane_ & 1;
                     const double give = odd ? sa : sb;
                     const int glo = __builtin_amdgcn_update_dpp(0, __double2loint(give), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
                     const int ghi = __builtin_amdgcn_update_dpp(0, __double2hiint(give), 0xB1, 0xf, 0xf, true);
                     const double got = __hiloint2double(ghi, glo);
                     const double2 v = odd ? make_double2(got, sb) : make_double2(sa, got);
-                    const int col = odd ? 63 + lane : lane;
+                    const int col = odd ? 63 + lane_ : lane_;
                     if (col + 1 < TN) *reinterpret_cast<double2 *>(o + col) = v;
                 }
             }
@@ -668,9 +690,9 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         }
         // carry the last HALO C rows over to the next step: read before the barrier, write after it
         double2 hv = make_double2(0.0, 0.0);
-        if (copier) hv = *reinterpret_cast<const double2 *>(halo_src);
+        if (copier_) hv = *reinterpret_cast<const double2 *>(halo_src_);
         lds_barrier();
-        if (copier) *reinterpret_cast<double2 *>(halo_dst) = hv;
+        if (copier_) *reinterpret_cast<double2 *>(halo_dst_) = hv;
     };
     const bool full_strip = (j0 + TN <= N) && ((o_pitch & 1) == 0) && ((o_off & 1) == 0);   // block-uniform
     step(0, std::true_type{});
