@@ -379,12 +379,13 @@ constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // gfx9 raw buffer: 32-bit da
 // 3 = no MFMA phase (stale LDS contents summed)
 // CSM_LAYOUT: write at the pair's csm_off / csm_pitch instead of crp_off / crp_pitch (WIN = 1 with
 // SQRT_OUT is then exactly get_csm, CRPUtils.py:67-84).
-// PLANAR ("split-line" layout): the result occupies the bytes of the float64 matrix, but every aligned block of
-// 32 values (256 bytes) is stored as the 32 high words followed by the 32 low words of the values'
-// order-preserving keys (wave_ops.h:f64_key; the sums are >= +0.0, so that is the bit pattern with the sign
-// bit set): value number idx of the float64 layout has its high word at word 64 * (idx / 32) + idx % 32 and its
-// low word 32 words later.  The selection kernels then read only the high-word half of every block -- whole
-// 128-byte lines, 4 bytes per element -- while this kernel writes the same contiguous byte ranges as before.
+// PLANAR ("split-line" layout): the buffer has the extent of the float64 matrix, but of every aligned block of 32
+// values (256 bytes) only the first half is written: the 32 high words of the values' order-preserving keys
+// (wave_ops.h:f64_key; the sums are >= +0.0, so that is the upper half of the bit pattern with the sign bit set) --
+// value number idx of the float64 layout has its high word at word 64 * (idx / 32) + idx % 32.  The selection
+// kernels read exactly those halves (whole 128-byte lines, 4 bytes per element); the low words are needed for
+// ~0.1 % of the rows / columns only, which the fix-up kernel recomputes from the features.  Half the bytes of
+// the float64 form leave the chip.
 template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false, bool PLANAR = false>
 __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
                                                         const double *__restrict__ feats, const double *__restrict__ norms,
@@ -440,22 +441,10 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         *reinterpret_cast<double2 *>(xs_dst) = reinterpret_cast<const double2 *>(xsrc)[min((int)threadIdx.x, last_chunk)];
     __syncthreads();
 
-    const int ca = lane, cb = lane + 64;
-    const bool oka = ca < TN && j0 + ca < N, okb = cb < TN && j0 + cb < N;
-    const int cbr = okb ? cb : ca;
-    // per-lane read bases of this wave's ROWS_PER_WAVE output rows, and write base of its 16 C columns
-    const double *rda = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + ca;
-    const double *rdb = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + cbr;
-    double *wr = cbuf + (HALO + lk) * CRP_LD + 16 * wave + lr;
-    // diagonal-run form: this lane owns the two adjacent diagonals that start at columns dcol and dcol + 1 of
-    // the wave's first output row
-    const int dcol = 2 * lane - ROWS_PER_WAVE;
-    const double *rdd = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + dcol;
-    // halo copy: thread h < HALO*128 moves element h of rows [32, 32+HALO) to rows [0, HALO)
-    const bool copier = threadIdx.x < HALO * (CRP_CT / 2);
-    const int hrow = (2 * threadIdx.x) / CRP_CT, hcol = (2 * threadIdx.x) % CRP_CT;
-    double *halo_src = cbuf + ((copier ? STRIP_ROWS + hrow : 0)) * CRP_LD + hcol;
-    double *halo_dst = cbuf + (copier ? hrow : 0) * CRP_LD + hcol;
+    // (the per-lane read / write bases into cbuf, the diagonal-run start column, the halo-copy and x-loader roles are
+    // derived inside `step`, see there: rda / rdb / rdd = this wave's ROWS_PER_WAVE output rows at the lane's columns,
+    // wr = its 16 C columns, the lane owns the two adjacent diagonals starting at columns dcol, dcol + 1; thread
+    // h < HALO * 64 moves two elements of rows [32, 32 + HALO) to rows [0, HALO))
     const int64_t o_off = CSM_LAYOUT ? ds.csm_off : ds.crp_off;
     const int o_pitch = CSM_LAYOUT ? ds.csm_pitch : ds.crp_pitch;
     double *orow = out + o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;
@@ -577,55 +566,25 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     const int soff = 8 * (ridx & ~31);
                     const int pb = ridx & 31;
                     auto hw = [&](const int c) { const int u = pb + c; return 4 * (u + (u & ~31)); };
-                    const uint32_t ha = (uint32_t)__double2hiint(sa) | 0x80000000u, la = (uint32_t)__double2loint(sa);
-                    const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u, lb = (uint32_t)__double2loint(sb);
+                    // only the high words leave the kernel (the low-word half of every block stays unwritten: the
+                    // selection needs it for ~0.1 % of the rows / columns, and the fix-up kernel recomputes those
+                    // values from the features instead) -- half the bytes of the float64 form
+                    const uint32_t ha = (uint32_t)__double2hiint(sa) | 0x80000000u;
+                    const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u;
                     if (CHECKED) {
                         const bool row_ok = gi >= 0 && gi < M;
-                        if (row_ok && col >= 0 && col < TN && j0 + col < N) {
-                            __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(la, orsrc, hw(col) + 128, soff, 0);
-                        }
-                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) {
-                            __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, 0);
-                            __builtin_amdgcn_raw_buffer_store_b32(lb, orsrc, hw(col + 1) + 128, soff, 0);
-                        }
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, 0);
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, 0);
                     } else {
-                        // this lane_'s pair of the row: columns ps, ps + 1 (ps even)
-                        uint32_t h0 = ha, h1 = hb, l0 = la, l1 = lb;
+                        // this lane's pair of the row: columns ps, ps + 1 (ps even): one 8-byte store, 16 lanes per 128-byte line
+                        uint32_t h0 = ha, h1 = hb;
                         int ps = col;
                         if ((q & 1) != 0) {
-                            h0 = hb; l0 = lb;
+                            h0 = hb;
                             h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x130, 0xf, 0xf, true);   // wave_shl:1
-                            l1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)la, 0x130, 0xf, 0xf, true);
                             ps = col + 1;
                         }
-                        if (quad_ok) {
-                            // two neighbouring lanes hold four adjacent columns: the one whose pair starts the
-                            // aligned quad writes the four high words (16 bytes to plane 0), the other one the
-                            // four low words (plane 1) -- one 16-byte store per lane_ and row, as in the float64 form
-                            const int EQ = (q & 1) ? q - (ROWS_PER_WAVE - 1) : q - ROWS_PER_WAVE;      // ps = 2 * lane_ + EQ (constant after unrolling)
-                            uint32_t g0, g1;
-                            bool leader;
-                            if ((EQ & 3) == 0) {
-                                leader = (lane_ & 1) == 0;
-                                g0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l0 : h0), 0xB1, 0xf, 0xf, true);   // quad_perm [1,0,3,2]
-                                g1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)(leader ? l1 : h1), 0xB1, 0xf, 0xf, true);
-                            } else {
-                                leader = (lane_ & 1) != 0;
-                                const uint32_t a0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h0, 0x130, 0xf, 0xf, true);      // from lane_ + 1
-                                const uint32_t a1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)h1, 0x130, 0xf, 0xf, true);
-                                const uint32_t b0 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l0, 0x138, 0xf, 0xf, true);      // from lane_ - 1
-                                const uint32_t b1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)l1, 0x138, 0xf, 0xf, true);
-                                g0 = leader ? a0 : b0;
-                                g1 = leader ? a1 : b1;
-                            }
-                            const int qs = leader ? ps : ps - 2;
-                            const u32x4_t v = leader ? (u32x4_t){h0, h1, g0, g1} : (u32x4_t){g0, g1, l0, l1};
-                            if (qs >= 0 && qs < TN) __builtin_amdgcn_raw_buffer_store_b128(v, orsrc, hw(qs) + (leader ? 0 : 128), soff, 0);
-                        } else if (ps >= 0 && ps < TN) {
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, orsrc, hw(ps), soff, 0);
-                            __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){l0, l1}, orsrc, hw(ps) + 128, soff, 0);
-                        }
+                        if (ps >= 0 && ps < TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, orsrc, hw(ps), soff, 0);
                     }
                 } else {
                     const int soff = 8 * (orow0 + (t * STRIP_ROWS + q) * o_pitch);      // wave-uniform byte offset of (row, strip column 0)

@@ -6,7 +6,8 @@
 // Why: the selection kernels of crp_kernels.hip run at 75 % of their load-only time -- they are bound by
 // reading 8 bytes per element of T, twice (rows, columns).  The k-th smallest of a row is decided by the high
 // words alone unless another element shares the winner's high word (~6e-4 of the rows at 992 columns); those
-// rows and columns go to the fix-up kernel, which reads both words.  So the two big kernels read 4 bytes per
+// rows and columns go to the fix-up kernel, which recomputes their exact values from the features (the strip
+// kernel does not write the low words at all: half the bytes).  So the two big kernels read 4 bytes per
 // element (whole 128-byte lines), hold 16 instead of 32 registers of data per lane, and need no key
 // conversion.
 //
@@ -131,7 +132,10 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
             ch = in ? h[e] : ch;
         }
         if (dup == 0) break;
-        if (shift == 0) return res;         // equal high words: both planes needed, fix-up pass
+        if (shift == 0) {                   // equal high words in one lane: exact values needed, fix-up pass
+            res.thr_key = (uint64_t)(lo + bstar) << 32;       // (tells it which high word the ties share)
+            return res;
+        }
         lo += bstar << shift;
         shift = max(shift - HIST_LOG2, 0);
         kind = REFINE;
@@ -151,8 +155,11 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
     const uint64_t win = __ballot(mine & (less < r) & (r <= less + equal));
     if (win == 0) return res;
     const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)win) - 1);
-    if (__builtin_amdgcn_readlane(equal, wl) > 1) return res;       // shared high word: low words decide
     const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)ch, wl);
+    if (__builtin_amdgcn_readlane(equal, wl) > 1) {                 // shared high word: exact values decide, fix-up pass
+        res.thr_key = (uint64_t)th << 32;
+        return res;
+    }
     res.thr_key = ((uint64_t)th << 32) | 0xffffffffull;
     res.cut = 0x7fffffff;
     warm.hi = th;
@@ -342,8 +349,29 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
 }
 
 // ---- fix-up: rows / columns whose winner shares its high word -----------------------------------------------
+// One windowed sum, exactly as crp_strip_kernel forms it: dot product as an FMA chain over the bins of the rolled
+// x frame, C = max(fma(-2, dot, |x|^2 + |y|^2), 0), the window's C values added in order (the matrix-core and VALU
+// forms of that chain agree bit for bit: tests/test_gpu_fast_path.py).
+__device__ inline double planar_exact_value(const double *__restrict__ feats, const double *__restrict__ norms, int d,
+                                            const acoss_pair_desc &ds, int win, int i, int j)
+{
+    double s = 0.0;
+    for (int k = 0; k < win; k++) {
+        const double *x = feats + (ds.x_row0 + i + k) * d, *y = feats + (ds.y_row0 + j + k) * d;
+        double acc = 0.0;
+        for (int b = 0; b < d; b++) {
+            int src = b - ds.shift;
+            if (src < 0) src += d;
+            acc = fma(x[src], y[b], acc);
+        }
+        s += fmax(fma(-2.0, acc, norms[ds.x_row0 + i + k] + norms[ds.y_row0 + j + k]), 0.0);
+    }
+    return s;
+}
+
 template <int DIR>
-__global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi,
+__global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
+                                                               const double *__restrict__ norms, int d,
                                                                const acoss_pair_desc *__restrict__ descs, int win,
                                                                double kv, int k_mode, ThreshWork w, int groups)
 {
@@ -362,14 +390,21 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
     while (todo) {
         const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
         todo &= todo - 1;
+        // the selection kernel left the high word the tied elements share: only those few need their exact value;
+        // every other element is ordered by its high word alone
+        const unsigned th = (unsigned)(thr[which] >> 32);
         uint64_t key[16];
         int idx[16];
 #pragma unroll
         for (int e = 0; e < 16; e++) {
             idx[e] = e * 64 + lane;
             const int q = min(idx[e], len - 1);
-            const int64_t at = planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which));
-            key[e] = idx[e] < len ? (((uint64_t)Thi[at] << 32) | Thi[at + 32]) : ~0ull;
+            const unsigned h = Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
+            uint64_t kx = (uint64_t)h << 32;
+            if (th == 0u || h == th)
+                kx = f64_key(DIR == 0 ? planar_exact_value(feats, norms, d, ds, win, which, q)
+                                      : planar_exact_value(feats, norms, d, ds, win, q, which));
+            key[e] = idx[e] < len ? kx : ~0ull;
         }
         const SelectResult res = wave_select_kth<16>(key, idx, len, k);
         if (lane == 0) {
@@ -401,11 +436,12 @@ static void kappa_mode_planar(double kappa, double &kv, int &mode)
     else { kv = kappa; mode = 1; }                   // :192-193
 }
 
-static int run_planar(int probe, const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+static int run_planar(int probe, const uint32_t *planes, const double *feats, const double *norms, int d,
+                      const acoss_pair_desc *descs, int K, int win,
                       int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes,
                       hipStream_t st)
 {
-    if (!planes || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
+    if (!planes || !feats || !norms || d < 1 || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
         set_error("mask_bits_planar: bad argument");
         return ACOSS_EINVAL;
     }
@@ -442,7 +478,7 @@ static int run_planar(int probe, const uint32_t *planes, const acoss_pair_desc *
         if (rc) return rc;
         if (probe == 2) return ACOSS_OK;
         const int groups = ceil_div(max_m, 64);
-        hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, descs, win, kv, mode, w, groups);
+        hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups);
         rc = launch_check("select_fix_planar_kernel<rows>");
         if (rc) return rc;
     }
@@ -453,7 +489,7 @@ static int run_planar(int probe, const uint32_t *planes, const acoss_pair_desc *
         if (rc) return rc;
         if (probe == 12) return ACOSS_OK;
         const int groups = ceil_div(max_n, 64);
-        hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, descs, win, kv, mode, w, groups);
+        hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups);
         rc = launch_check("select_fix_planar_kernel<cols>");
         if (rc) return rc;
     }
@@ -466,21 +502,23 @@ using namespace acoss;
 
 extern "C" {
 
-int acoss_mask_bits_planar_batch(const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, const double *norms, int d,
+                                 const acoss_pair_desc *descs, int K, int win,
                                  int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
                                  size_t work_bytes, void *stream)
 {
     if (!bits) { set_error("mask_bits_planar_batch: bad argument"); return ACOSS_EINVAL; }
-    return run_planar(0, planes, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, work_bytes,
+    return run_planar(0, planes, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, work_bytes,
                       (hipStream_t)stream);
 }
 
 // development probe (not part of the public ABI): 1 = row loads only, 2 = row selection kernel alone,
 // 11 = column loads only, 12 = column selection kernel alone
-int acoss_dev_planar_probe(int probe, const uint32_t *planes, const acoss_pair_desc *descs, int K,
+int acoss_dev_planar_probe(int probe, const uint32_t *planes, const double *feats, const double *norms, int d,
+                           const acoss_pair_desc *descs, int K,
                            int win, int max_nx, int max_ny, double kappa, void *work, size_t work_bytes, void *stream)
 {
-    return run_planar(probe, planes, descs, K, win, max_nx, max_ny, kappa, 1, nullptr, work, work_bytes,
+    return run_planar(probe, planes, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, 1, nullptr, work, work_bytes,
                       (hipStream_t)stream);
 }
 

@@ -197,8 +197,8 @@ def crp(corpus, batch, xp, sqrt_out=False, out=None, force_valu=False, force_til
 
 
 def crp_planar(corpus, batch, xp, out=None):
-    """The windowed sums of crp() in the split-line layout (every aligned block of 32 values = 32 high words +
-    32 low words of the order-preserving keys; include/acoss_mi355x.h) -- the input of mask_bits_planar().
+    """The key high words of the windowed sums of crp(), split-line layout (every aligned block of 32 values = 32 high
+    words + 32 unwritten words; include/acoss_mi355x.h) -- the input of mask_bits_planar().
     int32 tensor of 2 * planar_elems(batch) words.  float64 features, win == 9, d in {12, 13}."""
     lib = _lib.load()
     if out is None:
@@ -290,8 +290,9 @@ def mask_bits(S_buf, batch, kappa, mutual=True, out=None, work=None):
     return out, work
 
 
-def mask_bits_planar(planes, batch, kappa, mutual=True, out=None, work=None):
-    """mask_bits() from the two-plane form of crp_planar(): identical result, half the bytes read."""
+def mask_bits_planar(planes, corpus, batch, kappa, mutual=True, out=None, work=None):
+    """mask_bits() from the key high words of crp_planar() (the corpus and the batch they were built from): identical
+    result, half the bytes written and read."""
     lib = _lib.load()
     max_m = batch.max_nx - batch.win + 1
     if out is None:
@@ -299,7 +300,8 @@ def mask_bits_planar(planes, batch, kappa, mutual=True, out=None, work=None):
     need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
     if work is None or work.numel() < need:
         work = torch.empty(need, dtype=torch.uint8, device=planes.device)
-    check(lib.acoss_mask_bits_planar_batch(_ptr(planes), _ptr(batch.descs_dev), batch.K, batch.win,
+    check(lib.acoss_mask_bits_planar_batch(_ptr(planes), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                           _ptr(batch.descs_dev), batch.K, batch.win,
                                            batch.max_nx, batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out),
                                            _ptr(work), work.numel(), _stream()), "mask_bits_planar_batch")
     return out, work
@@ -415,7 +417,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         if planar_supported(corpus, batch):
             # same bytes as T, viewed as the two uint32 planes
             planes = crp_planar(corpus, batch, xp, out=T[:planar_elems(batch)].view(torch.int32))
-            bits, work = mask_bits_planar(planes, batch, kappa, mutual=True, work=work)
+            bits, work = mask_bits_planar(planes, corpus, batch, kappa, mutual=True, work=work)
         else:
             crp(corpus, batch, xp, sqrt_out=False, out=T)
         if planar_supported(corpus, batch) or bits_path_supported(batch):

@@ -146,7 +146,9 @@ class Runner(object):
         ny = [b.descs["ny"].astype(np.float64) for b in batches]
         # algorithmic bytes per launch of the cross-similarity kernel of each path
         self.csm_bytes = [float(np.sum(es * (x * y + corpus.d * (x + y)))) for x, y in zip(nx, ny)]
-        self.crp_bytes = [float(np.sum(8.0 * (x - m + 1) * (y - m + 1) + es * corpus.d * (x + y))) for x, y in zip(nx, ny)]
+        # the fast path's strip kernel writes 4 bytes per cell (key high words), the float64 form 8
+        cell = 4.0 if self.planar else 8.0
+        self.crp_bytes = [float(np.sum(cell * (x - m + 1) * (y - m + 1) + es * corpus.d * (x + y))) for x, y in zip(nx, ny)]
 
     def step(self, i, scores_out, ev=None):
         e = self.engine
@@ -168,7 +170,7 @@ class Runner(object):
             planes = self.S[:e.planar_elems(b)].view(torch.int32)
             e.crp_planar(self.corpus, b, self.xp, out=planes)
             mark(3)
-            e.mask_bits_planar(planes, b, self.kappa, True, out=self.bits2[slot], work=self.work)
+            e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits2[slot], work=self.work)
             mark(4)
             self.ready[slot].record(main)
             with torch.cuda.stream(self.side):
@@ -195,7 +197,7 @@ class Runner(object):
         mark(3)
         if self.path == "fast":
             if self.planar:
-                e.mask_bits_planar(planes, b, self.kappa, True, out=self.bits, work=self.work)
+                e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
             else:
                 e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
             mark(4)
@@ -305,7 +307,7 @@ def main():
             traffic = round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9)
             traffic_src = "profiles/r01_planar_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
     if runner.planar:
-        kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, split-line key words out)"
+        kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
         "value": round(value, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,

@@ -185,14 +185,15 @@ int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
 
-/* The same windowed sums (win == 9, d in {12, 13}, float64) in the "split-line" layout: the result occupies
- * the bytes of the float64 matrix, but every aligned block of 32 values (256 bytes) holds the 32 high words
- * followed by the 32 low words of the values' order-preserving keys (the IEEE bit pattern with the sign bit
- * set; the sums are >= +0.0).  Value number idx = crp_off + i * crp_pitch + j of the float64 layout has its
- * high word at word 64 * (idx / 32) + idx % 32 of `out` and its low word 32 words later.  The kNN selection
- * (acoss_mask_bits_planar_batch) then reads 4 bytes per element in whole 128-byte lines.  `out` needs the
- * float64 extent rounded up to a multiple of 32 values; plan the pairs with pitch_align = 32 so that rows
- * start on block boundaries (other pitches work, slower). */
+/* The same windowed sums (win == 9, d in {12, 13}, float64) as order-preserving key HIGH WORDS in the
+ * "split-line" layout: the buffer has the extent of the float64 matrix, every aligned block of 32 values
+ * (256 bytes) starts with the 32 high words (the IEEE bit pattern's upper half with the sign bit set; the sums are
+ * >= +0.0) -- value number idx = crp_off + i * crp_pitch + j has its high word at word 64 * (idx / 32) + idx % 32
+ * of `out`.  The other 128 bytes of each block are not written: the kNN selection (acoss_mask_bits_planar_batch)
+ * is decided by the high words for all but ~0.1 % of the rows / columns and recomputes those from the features.
+ * Half the bytes of acoss_crp_batch_f64, read back in whole 128-byte lines.  `out` needs the float64 extent
+ * rounded up to a multiple of 32 values; plan the pairs with pitch_align = 32 so that rows start on block
+ * boundaries (other pitches work, slower). */
 int acoss_crp_planar_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                                const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                                uint32_t *out, void *stream);
@@ -239,11 +240,13 @@ size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win);
 int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                           double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);
 
-/* The same bit-packed mask from the split-line form written by acoss_crp_planar_batch_f64 (same work and bits
- * sizes as acoss_mask_bits_batch).  The row and column selections read only the high words; rows or columns
- * whose k-th smallest value shares its high word with another element are finished from both words.
+/* The same bit-packed mask from the high words written by acoss_crp_planar_batch_f64 (same work and bits
+ * sizes as acoss_mask_bits_batch).  Rows or columns whose k-th smallest value shares its high word with another
+ * element are finished exactly: their values are recomputed from the features (feats, norms, d and the descriptors'
+ * shifts must be the ones the high words were built from) with the arithmetic of the strip kernel.
  * Results are identical to acoss_mask_bits_batch on the float64 matrix. */
-int acoss_mask_bits_planar_batch(const uint32_t *planes, const acoss_pair_desc *descs, int K, int win,
+int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, const double *norms, int d,
+                                 const acoss_pair_desc *descs, int K, int win,
                                  int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
                                  void *work, size_t work_bytes, void *stream);
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win,

@@ -187,7 +187,7 @@ def _planar_value_words(planes, idx):
 
 
 def test_planar_planes_decode_to_float64_result(eng, golden):
-    """crp_planar writes exactly the bits of crp(): high plane | low plane == key of the float64 value."""
+    """crp_planar writes exactly the high words of crp()'s values (order-preserving keys), in the split-line layout."""
     import torch
     from acoss_amd import synth
     g = golden("pairs_1000")
@@ -207,9 +207,9 @@ def test_planar_planes_decode_to_float64_result(eng, golden):
             d = batch.descs[p]
             M, N = d["nx"] - 8, d["ny"] - 8
             idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
-            gh, gl = _planar_value_words(planes, idx)
-            rh, rl = _planar_value_words(want, idx)
-            assert np.array_equal(gh, rh) and np.array_equal(gl, rl), p
+            gh, _ = _planar_value_words(planes, idx)
+            rh, _ = _planar_value_words(want, idx)
+            assert np.array_equal(gh, rh), p
 
 
 def test_planar_mask_equals_float64_mask(eng, golden):
@@ -232,27 +232,32 @@ def test_planar_mask_equals_float64_mask(eng, golden):
         for mutual in (True, False):
             for kappa in (0.095, 0.5, 3, 0):
                 want, _ = eng.mask_bits(T, batch, kappa, mutual=mutual)
-                got, _ = eng.mask_bits_planar(planes, batch, kappa, mutual=mutual)
+                got, _ = eng.mask_bits_planar(planes, corpus, batch, kappa, mutual=mutual)
                 for p in range(batch.K):
                     assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (p, mutual, kappa)
-    # crafted values on the layout of the golden batch: few distinct high words, many exact ties, negatives
-    corpus = eng.DeviceCorpus(g["feats"], g["frame_off"], gchroma=g["gchroma"])
-    batch = eng.PairBatch(corpus.frame_off, g["pairs"], 9, corpus.device, pitch_align=32)
+    # songs crafted so that the k-th smallest value is an exact tie (periodic frames: every row holds a handful of
+    # distinct values, each many times) or shares its high word with its neighbours (copies of a song with 1e-11
+    # perturbations): those rows and columns go through the fix-up kernel, which recomputes them from the features
     rng = np.random.default_rng(5)
-    n = batch.total_crp
-    crafted = [
-        1.0 + rng.integers(0, 1 << 20, n) * 2.0 ** -52,                      # one high word, distinct low words
-        rng.integers(0, 7, n).astype(np.float64),                             # seven values: ties everywhere
-        np.round(rng.standard_normal(n), 2),                                  # negatives, zeros (+0.0 / -0.0), ties
-        rng.integers(0, 50, n) + rng.integers(0, 4, n) * 2.0 ** -40,          # shared high words near every rank
-    ]
-    for vals in crafted:
-        T = torch.from_numpy(np.ascontiguousarray(vals)).to(corpus.device)
-        planes = _planes_of(T)
+    pat7, pat5 = rng.random((7, 12)) + 0.1, rng.random((5, 12)) + 0.1
+    A = np.tile(pat7, (30, 1))[:200]
+    Bs = np.tile(pat5, (31, 1))[:151]
+    C = A + 1e-11 * rng.random(A.shape)
+    Dn = Bs + 1e-11 * rng.random(Bs.shape)
+    feats = np.concatenate([A, Bs, C, Dn])
+    off = np.cumsum([0, len(A), len(Bs), len(C), len(Dn)]).astype(np.int64)
+    corpus = eng.DeviceCorpus(feats, off, gchroma=np.stack([x.sum(0) / x.sum(0).max() for x in (A, Bs, C, Dn)]))
+    pairs = np.array([(i, j) for i in range(4) for j in range(4)], dtype=np.int32)
+    for align in (32, 2):
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+        eng.oti(corpus, batch)
+        xp = eng.pack_x(corpus, batch)
+        T = eng.crp(corpus, batch, xp)
+        planes = eng.crp_planar(corpus, batch, xp)
         for mutual in (True, False):
             want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
-            got, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=mutual)
-            assert torch.equal(got, want), mutual
+            got, _ = eng.mask_bits_planar(planes, corpus, batch, 0.095, mutual=mutual)
+            assert torch.equal(got, want), (align, mutual)
 
 
 def test_smith_waterman_from_bits_equals_from_bytes(eng, golden):
@@ -289,11 +294,11 @@ def test_full_size_properties(eng, orc):
     batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
     xp = eng.pack_x(corpus, batch)                       # no OTI: shifts stay 0
     planes = eng.crp_planar(corpus, batch, xp)
-    rows_only, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=False)
-    mutual, _ = eng.mask_bits_planar(planes, batch, 0.095, mutual=True)
+    rows_only, _ = eng.mask_bits_planar(planes, corpus, batch, 0.095, mutual=False)
+    mutual, _ = eng.mask_bits_planar(planes, corpus, batch, 0.095, mutual=True)
     swapped = eng.PairBatch(corpus.frame_off, pairs[:, ::-1].copy(), 9, corpus.device, pitch_align=32)
     planes_t = eng.crp_planar(corpus, swapped, eng.pack_x(corpus, swapped))
-    cols_only_t, _ = eng.mask_bits_planar(planes_t, swapped, 0.095, mutual=False)       # rows of the transposed pair = columns
+    cols_only_t, _ = eng.mask_bits_planar(planes_t, corpus, swapped, 0.095, mutual=False)       # rows of the transposed pair = columns
     for p in range(0, 48, 5):
         R = eng.unpack_mask_bits(rows_only, batch, p)
         Ct = eng.unpack_mask_bits(cols_only_t, swapped, p)
@@ -303,7 +308,7 @@ def test_full_size_properties(eng, orc):
     q = eng.align_bits("qmax", mutual, batch).cpu().numpy()
     d = eng.align_bits("dmax", mutual, batch, boundary=1).cpu().numpy()
     assert np.all(q * 2 == np.round(q * 2)) and np.all(d * 2 == np.round(d * 2)) and np.all(d >= q)
-    mutual_t, _ = eng.mask_bits_planar(planes_t, swapped, 0.095, mutual=True)
+    mutual_t, _ = eng.mask_bits_planar(planes_t, corpus, swapped, 0.095, mutual=True)
     assert np.array_equal(eng.align_bits("qmax", mutual_t, swapped).cpu().numpy(), q)
     fast = eng.serra09_scores(corpus, pairs, do_oti=True)
     staged = eng.serra09_scores_staged(corpus, pairs, do_oti=True)

@@ -20,8 +20,8 @@ for align in (32, 16):
         idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
         a, b = ref[idx], got[idx]
         w = (idx >> 5) * 64 + (idx & 31)
-        key = (planes[w] << 32) | planes[w + 32]
-        bits = a.view(np.uint64) | (1 << 63)
+        key = planes[w]
+        bits = (a.view(np.uint64) | (1 << 63)) >> 32
         bad1 = np.argwhere(a != b)
         bad2 = np.argwhere(key.astype(np.uint64) != bits)
         if len(bad1) or len(bad2):

@@ -16,7 +16,7 @@ lib = _lib.load()
 work = torch.empty(int(lib.acoss_mask_bits_work_bytes(K, 1000, 1000, 9)), dtype=torch.uint8, device=corpus.device)
 fn = lib.acoss_dev_planar_probe
 fn.restype = ctypes.c_int
-fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
 names = {1: "rows loads only", 2: "rows select", 11: "cols loads only", 12: "cols select"}
 res = {m: [] for m in names}
@@ -24,7 +24,7 @@ for rnd in range(5):
     for m in names:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        rc = fn(m, engine._ptr(planes), engine._ptr(batch.descs_dev), K, 9, 1000, 1000, 0.095, engine._ptr(work), work.numel(), engine._stream())
+        rc = fn(m, engine._ptr(planes), engine._ptr(corpus.feats), engine._ptr(corpus.norms), corpus.d, engine._ptr(batch.descs_dev), K, 9, 1000, 1000, 0.095, engine._ptr(work), work.numel(), engine._stream())
         assert rc == 0, rc
         e1.record(); torch.cuda.synchronize()
         if rnd: res[m].append(e0.elapsed_time(e1))
