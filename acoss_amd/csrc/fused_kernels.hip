@@ -379,13 +379,11 @@ constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // gfx9 raw buffer: 32-bit da
 // 3 = no MFMA phase (stale LDS contents summed)
 // CSM_LAYOUT: write at the pair's csm_off / csm_pitch instead of crp_off / crp_pitch (WIN = 1 with
 // SQRT_OUT is then exactly get_csm, CRPUtils.py:67-84).
-// PLANAR ("split-line" layout): the buffer has the extent of the float64 matrix, but of every aligned block of 32
-// values (256 bytes) only the first half is written: the 32 high words of the values' order-preserving keys
-// (wave_ops.h:f64_key; the sums are >= +0.0, so that is the upper half of the bit pattern with the sign bit set) --
-// value number idx of the float64 layout has its high word at word 64 * (idx / 32) + idx % 32.  The selection
-// kernels read exactly those halves (whole 128-byte lines, 4 bytes per element); the low words are needed for
-// ~0.1 % of the rows / columns only, which the fix-up kernel recomputes from the features.  Half the bytes of
-// the float64 form leave the chip.
+// PLANAR: instead of the float64 sums the kernel writes a uint32 matrix with the same element indexing (crp_off +
+// i * crp_pitch + j): the high words of the values' order-preserving keys (wave_ops.h:f64_key; the sums are >= +0.0,
+// so that is the upper half of the bit pattern with the sign bit set).  Half the bytes of the float64 form leave the
+// chip and the selection kernels read 4 bytes per element; the low words are needed for ~0.1 % of the rows /
+// columns only, whose tied elements the fix-up kernel recomputes from the features.
 template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false, bool PLANAR = false>
 __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
                                                         const double *__restrict__ feats, const double *__restrict__ norms,
@@ -448,20 +446,16 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     const int64_t o_off = CSM_LAYOUT ? ds.csm_off : ds.crp_off;
     const int o_pitch = CSM_LAYOUT ? ds.csm_pitch : ds.crp_pitch;
     double *orow = out + o_off + j0 + (int64_t)(wave * ROWS_PER_WAVE - HALO) * o_pitch;
-    const bool quad_ok = ((o_pitch & 3) == 0) && ((o_off & 3) == 0) && (TN % 4 == 0);   // block-uniform
     // The pair's result matrix as a raw buffer resource (diagonal-run form): every store is "wave-uniform byte
     // offset of the row (SGPR) + 32-bit lane offset", so no 64-bit address pairs live in VGPRs, and the hardware
-    // range check drops anything outside the matrix.  Planar: offsets count from the 32-value block that holds
-    // the matrix start.  (Time-neutral against plain pointer stores in a same-buffer A/B -- the strip kernel's
-    // time moves by up to 10 % with the placement of its output allocation, tools/align_probe.py -- but 12-16 fewer
-    // VGPRs.)
+    // range check drops anything outside the matrix.  (Time-neutral against plain pointer stores in a same-buffer
+    // A/B -- the strip kernel's time moves by up to 10 % with the placement of its output allocation,
+    // tools/align_probe.py -- but 12-16 fewer VGPRs.)
+    constexpr int OB = PLANAR ? 4 : 8;          // bytes per output cell
     const int o_rows = CSM_LAYOUT ? ds.nx : M;
-    const int64_t pblock0 = o_off & ~(int64_t)31;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        out + (PLANAR ? pblock0 : o_off), 0,
-        (int)(8 * (PLANAR ? (((o_off - pblock0) + (int64_t)o_rows * o_pitch + 31) & ~(int64_t)31) : (int64_t)o_rows * o_pitch)),
-        BUFFER_RSRC_WORD3);
-    const int orow0 = (wave * ROWS_PER_WAVE - HALO) * o_pitch + j0 + (PLANAR ? (int)(o_off - pblock0) : 0);   // element index of (first row of the wave, strip column 0)
+        reinterpret_cast<char *>(out) + OB * o_off, 0, (int)(OB * (int64_t)o_rows * o_pitch), BUFFER_RSRC_WORD3);
+    const int orow0 = (wave * ROWS_PER_WAVE - HALO) * o_pitch + j0;   // element index of (first row of the wave, strip column 0)
     static_assert(!PLANAR || ((TN + ROWS_PER_WAVE <= CRP_CT) && !SQRT_OUT && !CSM_LAYOUT), "planar output: diagonal-run form only");
 
     // x frames are fetched two steps ahead (registers), so their HBM latency spans a whole step
@@ -560,15 +554,9 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                 }
                 const int col = dcol_ + q;
                 if constexpr (PLANAR) {
-                    // row start = 32 A + pb (A, pb wave-uniform); strip column c sits u = pb + c values into block A:
-                    // high word at byte 256 A + 4 (u + (u & ~31)), low word 128 bytes later
-                    const int ridx = orow0 + (t * STRIP_ROWS + q) * o_pitch;
-                    const int soff = 8 * (ridx & ~31);
-                    const int pb = ridx & 31;
-                    auto hw = [&](const int c) { const int u = pb + c; return 4 * (u + (u & ~31)); };
-                    // only the high words leave the kernel (the low-word half of every block stays unwritten: the
-                    // selection needs it for ~0.1 % of the rows / columns, and the fix-up kernel recomputes those
-                    // values from the features instead) -- half the bytes of the float64 form
+                    const int soff = 4 * (orow0 + (t * STRIP_ROWS + q) * o_pitch);      // wave-uniform byte offset of (row, strip column 0)
+                    auto hw = [&](const int c) { return 4 * c; };
+                    // only the high words leave the kernel: half the bytes of the float64 form
                     const uint32_t ha = (uint32_t)__double2hiint(sa) | 0x80000000u;
                     const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u;
                     if (CHECKED) {
@@ -576,7 +564,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                         if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, 0);
                         if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, 0);
                     } else {
-                        // this lane's pair of the row: columns ps, ps + 1 (ps even): one 8-byte store, 16 lanes per 128-byte line
+                        // this lane's pair of the row: columns ps, ps + 1 (ps even): one 8-byte store, 512 contiguous bytes per wave
                         uint32_t h0 = ha, h1 = hb;
                         int ps = col;
                         if ((q & 1) != 0) {

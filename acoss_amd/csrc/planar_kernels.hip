@@ -1,15 +1,12 @@
-// planar_kernels.hip -- kNN selection (CRPUtils.py:169-219) on the split-line form of the windowed sums
-// written by crp_strip_kernel<..., PLANAR>: every aligned block of 32 values of the float64 layout is stored as
-// 32 high words + 32 low words of the values' order-preserving keys (value idx: high word at word
-// 64 * (idx / 32) + idx % 32, low word 32 words later).
+// planar_kernels.hip -- kNN selection (CRPUtils.py:169-219) on the high words of the windowed sums' order-preserving
+// keys, the uint32 matrix written by crp_strip_kernel<..., PLANAR> (same element indexing as the float64 matrix).
 //
 // Why: the selection kernels of crp_kernels.hip run at 75 % of their load-only time -- they are bound by
 // reading 8 bytes per element of T, twice (rows, columns).  The k-th smallest of a row is decided by the high
 // words alone unless another element shares the winner's high word (~6e-4 of the rows at 992 columns); those
-// rows and columns go to the fix-up kernel, which recomputes their exact values from the features (the strip
-// kernel does not write the low words at all: half the bytes).  So the two big kernels read 4 bytes per
-// element (whole 128-byte lines), hold 16 instead of 32 registers of data per lane, and need no key
-// conversion.
+// rows and columns go to the fix-up kernel, which recomputes the exact values of the tied elements from the
+// features (the strip kernel does not write the low words at all).  So the two big kernels read 4 bytes per
+// element, hold 16 instead of 32 registers of data per lane, and need no key conversion.
 //
 // Outputs are the same as acoss_mask_bits_batch: thresholds (key = high word : 0xffffffff, which selects
 // exactly the same elements as the full key of the k-th smallest when its high word is unique), tie cuts,
@@ -166,8 +163,8 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
     return res;
 }
 
-// word index of the high word of float64 element idx (low word: + 32)
-__device__ inline int64_t planar_word(int64_t idx) { return ((idx >> 5) << 6) + (idx & 31); }
+// word index of element idx of the float64 layout
+__device__ inline int64_t planar_word(int64_t idx) { return idx; }
 
 __device__ inline bool planar_trivial(int k, int n, SelectResult &r)
 {
@@ -209,37 +206,22 @@ __global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32
     HistWarm warm{0, HIST_WARM_SHIFT0};
     const uint64_t valid = planar_slot_valid(N, lane);
     const bool wide = N > 15 * 64;       // wave-uniform: only the last slot can run past the row
-    // rows that start a 32-value block (pitch and offset multiples of 32): element e*64 + lane is word
-    // 128 e + lane + 32 (lane / 32) of the row -- two whole high-word lines per load instruction
-    const bool aligned = ((ds.crp_off & 31) == 0) && ((ds.crp_pitch & 31) == 0);
-    const unsigned lane_w = (unsigned)(lane + 32 * (lane >> 5));
     for (int i = r0; i < r1; i++) {
-        const int64_t idx0 = ds.crp_off + (int64_t)i * ds.crp_pitch;
+        const uint32_t *row = Thi + ds.crp_off + (int64_t)i * ds.crp_pitch;
         unsigned h[16];
-        if (aligned) {
-            const uint32_t *row = Thi + 2 * idx0;
-            if (wide) {
+        if (wide) {
+            // wave-uniform row pointer + one lane offset + immediates: 256 contiguous bytes per load instruction
 #pragma unroll
-                for (int e = 0; e < 15; e++) h[e] = row[(unsigned)(128 * e) + lane_w];
-                const int pl = min(15 * 64 + lane, N - 1);
-                h[15] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
-            } else {
-                // (cold paths: the lane number is laundered through an empty asm so that the sixteen address
-                // computations stay here instead of being hoisted, as 64-bit register pairs, in front of the
-                // row loop -- where they would set the register count of the whole kernel)
-                int lc = lane;
-                asm volatile("" : "+v"(lc));
-#pragma unroll
-                for (int e = 0; e < 16; e++) {
-                    const int pl = min(e * 64 + lc, N - 1);
-                    h[e] = row[(unsigned)(((pl >> 5) << 6) + (pl & 31))];
-                }
-            }
+            for (int e = 0; e < 15; e++) h[e] = row[(unsigned)(e * 64 + lane)];
+            h[15] = row[(unsigned)min(15 * 64 + lane, N - 1)];
         } else {
+            // (cold path: the lane number is laundered through an empty asm so that the sixteen clamped offsets are
+            // computed here instead of being hoisted in front of the row loop, where they would set the register
+            // count of the whole kernel)
             int lc = lane;
             asm volatile("" : "+v"(lc));
 #pragma unroll
-            for (int e = 0; e < 16; e++) h[e] = Thi[planar_word(idx0 + min(e * 64 + lc, N - 1))];
+            for (int e = 0; e < 16; e++) h[e] = row[(unsigned)min(e * 64 + lc, N - 1)];
         }
         if constexpr (MODE == 1) {
             unsigned acc = 0;
@@ -283,17 +265,15 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
         // 64 rows x 8 column pairs per sweep (8-byte loads, 64-byte row segments), 16 sweeps (M <= 1024).
         // (16-byte loads with 4 lanes per row segment take 2.3x as long: measured.)
         const int c2 = threadIdx.x & 7, rr = threadIdx.x >> 3;
-        // block-uniform: rows on 32-value block boundaries and a full column group -> wave-uniform base pointer
-        // + 32-bit word offsets (2 * row * pitch + the column's word inside its row)
-        const bool fast = ((ds.crp_pitch & 31) == 0) && ((ds.crp_off & 31) == 0) && (j0 + PL_COLS <= N);
+        // block-uniform: even pitch / offset (8-byte loads) and a full column group -> wave-uniform base pointer +
+        // 32-bit word offsets
+        const bool fast = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0) && (j0 + PL_COLS <= N);
         uint2 tmp[16];
         if (fast) {
-            const uint32_t *pb = Thi + 2 * ds.crp_off;
-            const int jc = j0 + 2 * c2;
-            const unsigned cw = (unsigned)(((jc >> 5) << 6) + (jc & 31));
+            const uint32_t *pb = Thi + ds.crp_off + j0 + 2 * c2;
 #pragma unroll
             for (int s = 0; s < 16; s++)
-                tmp[s] = *reinterpret_cast<const uint2 *>(pb + ((unsigned)(2 * min(s * 64 + rr, M - 1) * ds.crp_pitch) + cw));
+                tmp[s] = *reinterpret_cast<const uint2 *>(pb + (unsigned)(min(s * 64 + rr, M - 1) * ds.crp_pitch));
         } else {
             // (cold path; thread ids laundered so that its address arithmetic is not hoisted: see the row kernel)
             int cc = c2, rc = rr;
@@ -301,8 +281,8 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
 #pragma unroll
             for (int s = 0; s < 16; s++) {
                 const int64_t ri = ds.crp_off + (int64_t)min(s * 64 + rc, M - 1) * ds.crp_pitch;
-                tmp[s].x = Thi[planar_word(ri + min(j0 + 2 * cc + 0, N - 1))];
-                tmp[s].y = Thi[planar_word(ri + min(j0 + 2 * cc + 1, N - 1))];
+                tmp[s].x = Thi[ri + min(j0 + 2 * cc + 0, N - 1)];
+                tmp[s].y = Thi[ri + min(j0 + 2 * cc + 1, N - 1)];
             }
         }
 #pragma unroll

@@ -197,12 +197,11 @@ def crp(corpus, batch, xp, sqrt_out=False, out=None, force_valu=False, force_til
 
 
 def crp_planar(corpus, batch, xp, out=None):
-    """The key high words of the windowed sums of crp(), split-line layout (every aligned block of 32 values = 32 high
-    words + 32 unwritten words; include/acoss_mi355x.h) -- the input of mask_bits_planar().
-    int32 tensor of 2 * planar_elems(batch) words.  float64 features, win == 9, d in {12, 13}."""
+    """The key high words of the windowed sums of crp() as an int32 device vector with the float64 matrix's element
+    indexing (include/acoss_mi355x.h) -- the input of mask_bits_planar().  float64 features, win == 9, d in {12, 13}."""
     lib = _lib.load()
     if out is None:
-        out = torch.empty(2 * planar_elems(batch), dtype=torch.int32, device=corpus.device)
+        out = torch.empty(planar_elems(batch), dtype=torch.int32, device=corpus.device)
     check(lib.acoss_crp_planar_batch_f64(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
                                          _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny,
                                          _ptr(out), _stream()), "crp_planar_batch")
@@ -210,11 +209,11 @@ def crp_planar(corpus, batch, xp, out=None):
 
 
 def planar_elems(batch):
-    """float64 extent of the batch rounded up to whole 32-value blocks."""
-    return (max(batch.total_crp, 1) + 31) & ~31
+    """Words of the high-word matrix of a batch."""
+    return max(batch.total_crp, 2)
 
 
-PLANAR_PITCH_ALIGN = 32     # PairBatch(pitch_align=...) that puts every row on a block boundary
+PLANAR_PITCH_ALIGN = 32     # PairBatch(pitch_align=...) of the fast path: rows start on 128-byte lines
 
 
 def planar_supported(corpus, batch):
@@ -401,8 +400,8 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         if do_oti:
             oti(corpus, batch)
         xp = pack_x(corpus, batch, out=xp)
-        if T is None or T.numel() < planar_elems(batch):
-            T = torch.empty(planar_elems(batch), dtype=torch.float64, device=corpus.device)
+        if T is None or T.numel() < batch.total_crp:
+            T = torch.empty(max(batch.total_crp, 1), dtype=torch.float64, device=corpus.device)
             B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
         denom = (batch.M + batch.N).astype(np.float64)
         if "swc" in want and not (planar_supported(corpus, batch) or bits_path_supported(batch)):
@@ -415,8 +414,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                     out[kind][lo:lo + len(sel)] = align(kind, B, mats, **kw).cpu().numpy().astype(np.float64) / denom
             continue
         if planar_supported(corpus, batch):
-            # same bytes as T, viewed as the two uint32 planes
-            planes = crp_planar(corpus, batch, xp, out=T[:planar_elems(batch)].view(torch.int32))
+            planes = crp_planar(corpus, batch, xp, out=T.view(torch.int32)[:planar_elems(batch)])      # the first half of T's bytes
             bits, work = mask_bits_planar(planes, corpus, batch, kappa, mutual=True, work=work)
         else:
             crp(corpus, batch, xp, sqrt_out=False, out=T)

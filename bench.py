@@ -42,7 +42,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=4096,
-                    help="pairs per launch batch and GPU (4096 x 7.9 MB of windowed sums = 33 GB of the 288 GB)")
+                    help="pairs per launch batch and GPU (4096 x 3.9 MB of key high words = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--path", choices=("fast", "fast_f64", "staged"), default="fast",
@@ -87,7 +87,9 @@ class Runner(object):
         dev = corpus.device
         lib = engine._lib.load()
         tr = max(b.total_crp for b in batches)
-        self.S = torch.empty(tr + 32, dtype=torch.float64, device=dev)
+        # the big intermediate: float64 sums (8 B / cell), or their key high words on the fast path (4 B / cell)
+        s_elems = (tr // 2 + 32) if self.planar else (tr + 32)
+        self.S = torch.empty(s_elems, dtype=torch.float64, device=dev)
         self.B = torch.zeros(tr, dtype=torch.uint8, device=dev) if path == "staged" else None
         if path == "staged":
             self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
@@ -120,11 +122,11 @@ class Runner(object):
             cands, times = [self.S], []
             try:
                 for _ in range(2):
-                    cands.append(torch.empty(tr + 32, dtype=torch.float64, device=dev))
+                    cands.append(torch.empty(s_elems, dtype=torch.float64, device=dev))
             except RuntimeError:
                 pass
             for buf in cands:
-                planes = buf[:engine.planar_elems(b0)].view(torch.int32)
+                planes = buf.view(torch.int32)[:engine.planar_elems(b0)]
                 best = 1e9
                 for rep in range(3):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -167,7 +169,7 @@ class Runner(object):
             mark(1)
             e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            planes = self.S[:e.planar_elems(b)].view(torch.int32)
+            planes = self.S.view(torch.int32)[:e.planar_elems(b)]
             e.crp_planar(self.corpus, b, self.xp, out=planes)
             mark(3)
             e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits2[slot], work=self.work)
@@ -186,7 +188,7 @@ class Runner(object):
             e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
             if self.planar:
-                planes = self.S[:e.planar_elems(b)].view(self.torch.int32)
+                planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
                 e.crp_planar(self.corpus, b, self.xp, out=planes)
             else:
                 e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)

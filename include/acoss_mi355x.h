@@ -185,15 +185,12 @@ int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
 
-/* The same windowed sums (win == 9, d in {12, 13}, float64) as order-preserving key HIGH WORDS in the
- * "split-line" layout: the buffer has the extent of the float64 matrix, every aligned block of 32 values
- * (256 bytes) starts with the 32 high words (the IEEE bit pattern's upper half with the sign bit set; the sums are
- * >= +0.0) -- value number idx = crp_off + i * crp_pitch + j has its high word at word 64 * (idx / 32) + idx % 32
- * of `out`.  The other 128 bytes of each block are not written: the kNN selection (acoss_mask_bits_planar_batch)
- * is decided by the high words for all but ~0.1 % of the rows / columns and recomputes those from the features.
- * Half the bytes of acoss_crp_batch_f64, read back in whole 128-byte lines.  `out` needs the float64 extent
- * rounded up to a multiple of 32 values; plan the pairs with pitch_align = 32 so that rows start on block
- * boundaries (other pitches work, slower). */
+/* The same windowed sums (win == 9, d in {12, 13}, float64) as a uint32 matrix of order-preserving key HIGH
+ * WORDS (the IEEE bit pattern's upper half with the sign bit set; the sums are >= +0.0), indexed like the float64
+ * matrix: out[crp_off + i * crp_pitch + j].  Half the bytes of acoss_crp_batch_f64.  The kNN selection
+ * (acoss_mask_bits_planar_batch) is decided by the high words for all but ~0.1 % of the rows / columns and
+ * recomputes the tied elements of those from the features.  crp_off and crp_pitch even for the fast stores
+ * (acoss_plan_pairs with pitch_align >= 2). */
 int acoss_crp_planar_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                                const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                                uint32_t *out, void *stream);

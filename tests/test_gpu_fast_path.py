@@ -166,28 +166,17 @@ def test_bit_mask_path_equals_byte_mask_path(eng, golden):
                                       eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())
 
 
-def _planes_of(T):
-    """Split-line form of a float64 device vector: every block of 32 values -> 32 high words + 32 low words of
-    the order-preserving keys (include/acoss_mi355x.h, acoss_crp_planar_batch_f64)."""
+def _key_hi(T):
+    """High words of the order-preserving keys of a float64 device vector (include/acoss_mi355x.h,
+    acoss_crp_planar_batch_f64), as int64 numpy."""
     import torch
-    n = (T.numel() + 31) & ~31
-    v = torch.zeros(n, dtype=torch.float64, device=T.device)
-    v[:T.numel()] = T
-    b = (v + 0.0).view(torch.int64)
+    b = (T + 0.0).view(torch.int64)
     key = torch.where(b < 0, ~b, b | (-0x8000000000000000))
-    hi = (key >> 32).to(torch.int32)
-    lo = (key << 32 >> 32).to(torch.int32)
-    return torch.stack([hi.view(-1, 32), lo.view(-1, 32)], dim=1).reshape(-1).contiguous()
-
-
-def _planar_value_words(planes, idx):
-    """(high, low) words of float64 element numbers idx (numpy int64) from a host copy of the split-line buffer."""
-    w = (idx >> 5) * 64 + (idx & 31)
-    return planes[w], planes[w + 32]
+    return ((key >> 32) & 0xffffffff).cpu().numpy()
 
 
 def test_planar_planes_decode_to_float64_result(eng, golden):
-    """crp_planar writes exactly the high words of crp()'s values (order-preserving keys), in the split-line layout."""
+    """crp_planar writes exactly the high words of crp()'s values (order-preserving keys), indexed like the float64 matrix."""
     import torch
     from acoss_amd import synth
     g = golden("pairs_1000")
@@ -201,15 +190,14 @@ def test_planar_planes_decode_to_float64_result(eng, golden):
         eng.oti(corpus, batch)
         xp = eng.pack_x(corpus, batch)
         T = eng.crp(corpus, batch, xp)
-        planes = eng.crp_planar(corpus, batch, xp, out=torch.full((2 * eng.planar_elems(batch),), -1, dtype=torch.int32, device=corpus.device)).cpu().numpy()
-        want = _planes_of(T).cpu().numpy()
+        planes = eng.crp_planar(corpus, batch, xp, out=torch.full((eng.planar_elems(batch),), -1, dtype=torch.int32, device=corpus.device))
+        planes = planes.cpu().numpy().astype(np.int64) & 0xffffffff
+        want = _key_hi(T)
         for p in range(batch.K):
             d = batch.descs[p]
             M, N = d["nx"] - 8, d["ny"] - 8
             idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
-            gh, _ = _planar_value_words(planes, idx)
-            rh, _ = _planar_value_words(want, idx)
-            assert np.array_equal(gh, rh), p
+            assert np.array_equal(planes[idx], want[idx]), p
 
 
 def test_planar_mask_equals_float64_mask(eng, golden):

@@ -19,7 +19,7 @@ for name, lib in (("new", new), ("old", old)):
         fn = getattr(lib, fn_name)
         fn.restype = ctypes.c_int
         fn.argtypes = _lib.SIGNATURES[fn_name][1]
-one = torch.empty(2 * engine.planar_elems(batch), dtype=torch.int32, device=corpus.device)
+one = torch.empty(engine.planar_elems(batch) + 2 * batch.total_crp, dtype=torch.int32, device=corpus.device)
 bufs = {"new": one, "old": one}      # same output buffer: kernel time depends on the allocation
 def run(lib, which, out):
     if which == "planar":

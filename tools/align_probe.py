@@ -11,7 +11,7 @@ allp = synth.all_pairs(ch.n_songs)
 batch = engine.PairBatch(corpus.frame_off, allp[np.arange(K) % len(allp)], 9, corpus.device, pitch_align=32)
 engine.oti(corpus, batch)
 xp = engine.pack_x(corpus, batch)
-n = engine.planar_elems(batch)
+n = batch.total_crp
 big = torch.empty(2 * n + (64 << 20), dtype=torch.int32, device=corpus.device)
 print("base address %#x" % big.data_ptr())
 offs = [0, 64, 256, 1024, 4096, 16384, 65536, 1 << 18, 1 << 20, (1 << 20) + 4096, 3 << 20, 1 << 22, 1 << 24]

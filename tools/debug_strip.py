@@ -19,7 +19,7 @@ for align in (32, 16):
         M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
         idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
         a, b = ref[idx], got[idx]
-        w = (idx >> 5) * 64 + (idx & 31)
+        w = idx
         key = planes[w]
         bits = (a.view(np.uint64) | (1 << 63)) >> 32
         bad1 = np.argwhere(a != b)
