@@ -107,7 +107,9 @@ class Runner(object):
         # buffers, events both ways)
         self.overlap = bool(overlap) and self.planar
         if self.overlap:
-            self.bits2 = [self.bits, torch.zeros_like(self.bits)]
+            # two copies of the high-word matrix: the strip kernel of batch b + 1 (LDS / barrier-bound) runs on the main
+            # stream while the selection + alignment kernels of batch b (HBM / latency-bound) run on the side stream
+            self.S2 = [self.S, torch.empty(s_elems, dtype=torch.float64, device=dev)]
             self.side = torch.cuda.Stream(device=dev)
             self.ready = [torch.cuda.Event(), torch.cuda.Event()]
             self.free = [torch.cuda.Event(), torch.cuda.Event()]
@@ -136,6 +138,8 @@ class Runner(object):
                         best = min(best, e0.elapsed_time(e1))
                 times.append(best)
             self.S = cands[int(np.argmin(times))]
+            if self.overlap:
+                self.S2[0] = self.S
             self.placement_ms = [round(t, 3) for t in times]
             del cands
             torch.cuda.empty_cache()
@@ -163,21 +167,21 @@ class Runner(object):
             torch = self.torch
             slot = i & 1
             main = torch.cuda.current_stream()
-            main.wait_event(self.free[slot])          # the sweep that last read this mask buffer has finished
+            main.wait_event(self.free[slot])          # the selection that last read this copy has finished
             mark(0)
             e.oti(self.corpus, b)
             mark(1)
             e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            planes = self.S.view(torch.int32)[:e.planar_elems(b)]
+            planes = self.S2[slot].view(torch.int32)[:e.planar_elems(b)]
             e.crp_planar(self.corpus, b, self.xp, out=planes)
             mark(3)
-            e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits2[slot], work=self.work)
-            mark(4)
             self.ready[slot].record(main)
             with torch.cuda.stream(self.side):
                 self.side.wait_event(self.ready[slot])
-                e.align_bits("qmax", self.bits2[slot], b, scores=scores_out)
+                e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
+                mark(4)
+                e.align_bits("qmax", self.bits, b, scores=scores_out)
                 mark(5)
                 self.free[slot].record(self.side)
             return
