@@ -315,7 +315,8 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     HistWarm warm{0, HIST_WARM_SHIFT0};
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
-        if (!planar_trivial(k, M, res)) res = wave_select16_hist_u32(h, M, k, hist, lane, warm);
+        if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
+        else if (!planar_trivial(k, M, res)) res = wave_select16_hist_u32(h, M, k, hist, lane, warm);
         if (lane == 0) {
             w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
             w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
@@ -446,6 +447,11 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
     if (probe == 1) {
         hipLaunchKernelGGL(select_rows_planar_kernel<1>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
         return launch_check("select_rows_planar probe");
+    }
+    if (probe == 13) {      // column kernel without the selection itself (staging, reload, bit emission)
+        ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(select_cols_planar_kernel<2>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, planes, descs, win, kv, mode, w, cb);
+        return launch_check("select_cols_planar probe");
     }
     if (probe == 11) {
         ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
