@@ -365,6 +365,30 @@ def align(kind, B_buf, mats, D=None, boundary=0, params=None, max_cols=None, mat
 # ---------------------------------------------------------------------------------------------
 # the Serra09 chain
 # ---------------------------------------------------------------------------------------------
+_SCRATCH = {}
+
+
+def _scratch(name, numel, dtype, device, zero=False):
+    """Grow-only device scratch buffers shared by successive calls of the chain functions."""
+    key = (name, str(device), dtype)
+    buf = _SCRATCH.get(key)
+    if buf is None or buf.numel() < numel:
+        _SCRATCH.pop(key, None)
+        buf = None
+        torch.cuda.empty_cache() if numel * torch.empty((), dtype=dtype).element_size() > (1 << 30) else None
+        buf = (torch.zeros if zero else torch.empty)(int(numel * 1.05) + 16, dtype=dtype, device=device)
+        _SCRATCH[key] = buf
+    elif zero:
+        buf[:numel].zero_()
+    return buf[:numel]
+
+
+def release_scratch():
+    """Drop the cached scratch buffers (tests, memory-tight callers)."""
+    _SCRATCH.clear()
+    torch.cuda.empty_cache()
+
+
 def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None):
     """
     Serra09.py:166-175 for every pair, fast path: oti -> pack_x -> crp (fused CSM + sliding window,
@@ -391,21 +415,28 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                 out[k][part] = res[k]
         return out
     if batch_pairs is None:
+        # ~4096 pairs of 1000-frame songs per launch batch (34 GB of the 288): the one-wave-per-pair alignment kernel
+        # needs thousands of pairs in flight
         per_pair = float(max(lens[pairs[:, 0]].max(), lens[pairs[:, 1]].max())) ** 2 * 9.2
-        batch_pairs = int(max(1, min(K, (8 << 30) // max(per_pair, 1.0))))
-    xp = T = B = work = None
+        batch_pairs = int(max(1, min(K, (36 << 30) // max(per_pair, 1.0))))
     for lo in range(0, K, batch_pairs):
         sel = pairs[lo:lo + batch_pairs]
         batch = PairBatch(corpus.frame_off, sel, m, corpus.device, pitch_align=PLANAR_PITCH_ALIGN)
         if do_oti:
             oti(corpus, batch)
-        xp = pack_x(corpus, batch, out=xp)
-        if T is None or T.numel() < batch.total_crp:
-            T = torch.empty(max(batch.total_crp, 1), dtype=torch.float64, device=corpus.device)
-            B = torch.zeros(batch.total_crp, dtype=torch.uint8, device=corpus.device)
+        planar = planar_supported(corpus, batch)
+        # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
+        xp = pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
+        T = _scratch("T", (batch.total_crp + 1) // 2 + 1 if planar else max(batch.total_crp, 1), torch.float64, corpus.device)
+        work = _scratch("work", int(_lib.load().acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, m)), torch.uint8, corpus.device)
+        B = None if planar or bits_path_supported(batch) or fused_align_supported(batch) \
+            else _scratch("B", max(batch.total_crp, 1), torch.uint8, corpus.device, zero=True)
+        bits_buf = _scratch("bits", max(batch.K * (batch.max_nx - m + 1) * 16, 1), torch.int64, corpus.device) \
+            if (planar or bits_path_supported(batch)) else None
         denom = (batch.M + batch.N).astype(np.float64)
-        if "swc" in want and not (planar_supported(corpus, batch) or bits_path_supported(batch)):
+        if "swc" in want and not (planar or bits_path_supported(batch)):
             # matrices beyond 1024 x 1024: byte mask + dp_wave_kernel / dp_block_kernel
+            B = _scratch("B", max(batch.total_crp, 1), torch.uint8, corpus.device, zero=True)
             crp(corpus, batch, xp, sqrt_out=False, out=T)
             binarize(T, batch, kappa, mutual=True, out=B, work=work)
             mats, _ = batch.mats()
@@ -413,14 +444,14 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                 if kind in want:
                     out[kind][lo:lo + len(sel)] = align(kind, B, mats, **kw).cpu().numpy().astype(np.float64) / denom
             continue
-        if planar_supported(corpus, batch):
-            planes = crp_planar(corpus, batch, xp, out=T.view(torch.int32)[:planar_elems(batch)])      # the first half of T's bytes
-            bits, work = mask_bits_planar(planes, corpus, batch, kappa, mutual=True, work=work)
+        if planar:
+            planes = crp_planar(corpus, batch, xp, out=T.view(torch.int32)[:planar_elems(batch)])
+            bits, work = mask_bits_planar(planes, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
         else:
             crp(corpus, batch, xp, sqrt_out=False, out=T)
-        if planar_supported(corpus, batch) or bits_path_supported(batch):
-            if not planar_supported(corpus, batch):
-                bits, work = mask_bits(T, batch, kappa, mutual=True, work=work)
+        if planar or bits_path_supported(batch):
+            if not planar:
+                bits, work = mask_bits(T, batch, kappa, mutual=True, out=bits_buf, work=work)
             if "qmax" in want:
                 out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
             if "dmax" in want:
