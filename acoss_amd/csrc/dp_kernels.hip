@@ -634,6 +634,127 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
     if (lane == 0) scores[p] = best;
 }
 
+// qmax and dmax of the same mask in ONE sweep (what Serra09.similarity asks for, Serra09.py:173-175: dmax on the D
+// that qmax leaves behind = `boundary`): the two recurrences are independent given the mask rows, so their
+// dependent chains interleave in one instruction stream and the mask is read once.  Same arithmetic per kind as
+// dp_bits_kernel.
+__global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restrict__ bits,
+                                                         const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                         int max_m, float gamma, int boundary,
+                                                         float *__restrict__ qscores, float *__restrict__ dscores)
+{
+    constexpr int CPL = 16, PF = 16;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const bool do_q = M >= 3 && N >= 3, do_d = M >= 4 && N >= 4;      // SequenceAlignment.c:117-119 / 151-153
+    if (!do_q) {
+        if (lane == 0) { qscores[p] = 0.0f; dscores[p] = 0.0f; }
+        return;
+    }
+    const int j0 = lane * CPL;
+    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(1 + u, M - 1) * 64];
+    float q1[CPL], q2[CPL], e1[CPL], e2[CPL], e3[CPL];              // qmax rows i-1, i-2; dmax rows i-1, i-2, i-3
+#pragma unroll
+    for (int c = 0; c < CPL; c++) { q1[c] = q2[c] = e1[c] = e2[c] = e3[c] = 0.f; }
+    unsigned m1 = 0, m2 = 0;
+    float qbest = 0.0f, dbest = 0.0f;
+    const bool l0 = lane == 0;
+    auto do_row = [&](const int i, const unsigned m0) {
+        if (i >= 2) {       // ---- qmax (rows >= 2)
+            const float h1a = lane_shr1(q1[CPL - 1], 0.f), h1b = lane_shr1(q1[CPL - 2], 0.f);
+            const float h2a = lane_shr1(q2[CPL - 1], 0.f);
+            float nd[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; c++) {
+                const float p_diag = c >= 1 ? q1[c - 1] : h1a;
+                const float p_up2 = c >= 1 ? q2[c - 1] : h2a;
+                const float p_left2 = c >= 2 ? q1[c - 2] : (c == 1 ? h1a : h1b);
+                const bool on = (m0 >> c) & 1u;
+                float v = fmaxf(max3f(p_diag, p_up2, p_left2) + (on ? 1.0f : -gamma), 0.0f);
+                if (c < 2) {
+                    qbest = fmaxf(qbest, l0 ? 0.0f : v);
+                    v = l0 ? 0.0f : v;
+                } else {
+                    qbest = fmaxf(qbest, v);
+                }
+                nd[c] = v;
+            }
+#pragma unroll
+            for (int c = 0; c < CPL; c++) { q2[c] = q1[c]; q1[c] = nd[c]; }
+        }
+        if (do_d) {
+            if (i >= 3) {   // ---- dmax (rows >= 3)
+                const float h1a = lane_shr1(e1[CPL - 1], 0.f), h1b = lane_shr1(e1[CPL - 2], 0.f), h1c = lane_shr1(e1[CPL - 3], 0.f);
+                const float h2a = lane_shr1(e2[CPL - 1], 0.f), h3a = lane_shr1(e3[CPL - 1], 0.f);
+                const unsigned h0 = (unsigned)lane_shr1((int)m0, 0);
+                const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);
+                float nd[CPL];
+#pragma unroll
+                for (int c = 0; c < CPL; c++) {
+                    const float p_diag = c >= 1 ? e1[c - 1] : h1a;
+                    const float p_up2 = c >= 1 ? e2[c - 1] : h2a;
+                    const float p_left2 = c >= 2 ? e1[c - 2] : (c == 1 ? h1a : h1b);
+                    const float p_up3 = c >= 1 ? e3[c - 1] : h3a;
+                    const float p_left3 = c >= 3 ? e1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));
+                    const float s_u1 = (float)((m1 >> c) & 1u);
+                    const float s_u2 = (float)((m2 >> c) & 1u);
+                    const float s_l1 = (float)((ext >> (c + 1)) & 1u);
+                    const float s_l2 = (float)((ext >> c) & 1u);
+                    const float c2 = p_up2 + s_u1;
+                    const float c3 = p_left2 + s_l1;
+                    const float c4 = (p_up3 + s_u2) + s_u1;
+                    const float c5 = (p_left3 + s_l2) + s_l1;
+                    const float m = fmaxf(fmaxf(max3f(p_diag, c2, c3), c4), c5);
+                    const bool on = (m0 >> c) & 1u;
+                    float v = fmaxf(m + (on ? 1.0f : -gamma), 0.0f);
+                    if (c < 3) {
+                        const float bval = (c == 2 && boundary) ? (float)((m0 >> 2) & 1u) : 0.0f;
+                        dbest = fmaxf(dbest, l0 ? 0.0f : v);
+                        v = l0 ? bval : v;
+                    } else {
+                        dbest = fmaxf(dbest, v);
+                    }
+                    nd[c] = v;
+                }
+#pragma unroll
+                for (int c = 0; c < CPL; c++) { e3[c] = e2[c]; e2[c] = e1[c]; e1[c] = nd[c]; }
+            } else if (i == 2) {
+#pragma unroll
+                for (int c = 0; c < CPL; c++) e1[c] = (boundary && j0 + c >= 2) ? (float)((m0 >> c) & 1u) : 0.0f;
+            }
+        }
+        m2 = m1;
+        m1 = m0;
+    };
+    for (int ib = 1; ib < M; ib += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const int i = ib + u;
+            if (i < M) {
+                const unsigned m0 = ring[u];        // bits past column N are zero by construction
+                if (i + PF < M) ring[u] = rowp[(int64_t)(i + PF) * 64];
+                do_row(i, m0);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        qbest = fmaxf(qbest, __shfl_xor(qbest, off));
+        dbest = fmaxf(dbest, __shfl_xor(dbest, off));
+    }
+    if (lane == 0) {
+        qscores[p] = qbest;
+        dscores[p] = do_d ? dbest : 0.0f;
+    }
+}
+
 template <int KIND>
 static int launch_dp(const uint8_t *S, const acoss_mat_desc *mats, int K, int max_cols, float *D,
                      int boundary, const acoss_align_params *params, float *scores, hipStream_t st)
@@ -707,6 +828,27 @@ int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc
     else
         hipLaunchKernelGGL(dp_bits_kernel<KIND_SWC>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
     return launch_check("dp_bits_kernel");
+}
+
+int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                              int max_ny, int boundary, const acoss_align_params *params, float *qmax_scores,
+                              float *dmax_scores, void *stream)
+{
+    if (!bits || !descs || !qmax_scores || !dmax_scores || K < 0 || win < 1 || max_nx < win || max_ny < win) {
+        set_error("align_bits_qd_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    acoss_align_params ap;
+    if (params) ap = *params; else acoss_default_align_params(&ap);
+    if (max_n > 1024 || max_m > 1024 || ap.gamma_onset != ap.gamma_extension) {
+        set_error("align_bits_qd_batch: needs <= 1024 x 1024 matrices and gamma_onset == gamma_extension");
+        return ACOSS_ENOTSUP;
+    }
+    if (K == 0) return ACOSS_OK;
+    hipLaunchKernelGGL(dp_bits_qd_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m,
+                       ap.gamma_onset, boundary, qmax_scores, dmax_scores);
+    return launch_check("dp_bits_qd_kernel");
 }
 
 int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *descs, int K, int win, int max_nx,

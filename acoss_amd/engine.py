@@ -318,6 +318,17 @@ def align_bits(kind, bits, batch, boundary=0, params=None, scores=None):
     return scores[:batch.K]
 
 
+def align_bits_qd(bits, batch, boundary=1, params=None):
+    """(qmax, dmax) from the bit-packed mask in one sweep; boundary=1: dmax on the D qmax leaves (Serra09.py:173-175)."""
+    lib = _lib.load()
+    q = torch.empty(max(batch.K, 1), dtype=torch.float32, device=bits.device)
+    d = torch.empty(max(batch.K, 1), dtype=torch.float32, device=bits.device)
+    pp = ctypes.byref(params) if params is not None else None
+    check(lib.acoss_align_bits_qd_batch(_ptr(bits), _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny,
+                                        int(boundary), pp, _ptr(q), _ptr(d), _stream()), "align_bits_qd_batch")
+    return q[:batch.K], d[:batch.K]
+
+
 def bits_path_supported(batch):
     return batch.max_nx - batch.win + 1 <= 1024 and batch.max_ny - batch.win + 1 <= 1024
 
@@ -452,9 +463,13 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         if planar or bits_path_supported(batch):
             if not planar:
                 bits, work = mask_bits(T, batch, kappa, mutual=True, out=bits_buf, work=work)
-            if "qmax" in want:
+            if "qmax" in want and "dmax" in want:
+                q, d = align_bits_qd(bits, batch, boundary=1)
+                out["qmax"][lo:lo + len(sel)] = q.cpu().numpy().astype(np.float64) / denom
+                out["dmax"][lo:lo + len(sel)] = d.cpu().numpy().astype(np.float64) / denom
+            elif "qmax" in want:
                 out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
-            if "dmax" in want:
+            elif "dmax" in want:
                 out["dmax"][lo:lo + len(sel)] = align_bits("dmax", bits, batch, boundary=1).cpu().numpy().astype(np.float64) / denom
             if "swc" in want:
                 out["swc"][lo:lo + len(sel)] = align_bits("swc", bits, batch).cpu().numpy().astype(np.float64) / denom

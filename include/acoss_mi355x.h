@@ -249,6 +249,11 @@ int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, co
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win,
                            int max_nx, int max_ny, int boundary, const acoss_align_params *params,
                            float *scores, void *stream);
+/* qmax and dmax of the same bit mask in one sweep (Serra09.similarity's pair, Serra09.py:173-175; `boundary` = 1 is
+ * its dmax on the D qmax leaves behind): same results as the two acoss_align_bits_batch calls. */
+int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs, int K, int win, int max_nx,
+                              int max_ny, int boundary, const acoss_align_params *params, float *qmax_scores,
+                              float *dmax_scores, void *stream);
 
 /* SequenceAlignment.c:113 / :147 / :73 over a batch of matrices.  S and D are the bases the
  * descs' offsets refer to; D may be NULL (scores only: the reference's callers never read D,

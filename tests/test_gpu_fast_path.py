@@ -164,6 +164,9 @@ def test_bit_mask_path_equals_byte_mask_path(eng, golden):
             for boundary in (0, 1):
                 assert np.array_equal(eng.align_bits("dmax", bits, batch, boundary=boundary).cpu().numpy(),
                                       eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())
+                q, d = eng.align_bits_qd(bits, batch, boundary=boundary)          # both in one sweep
+                assert np.array_equal(q.cpu().numpy(), eng.align("qmax", B, mats).cpu().numpy())
+                assert np.array_equal(d.cpu().numpy(), eng.align("dmax", B, mats, boundary=boundary).cpu().numpy())
 
 
 def _key_hi(T):
