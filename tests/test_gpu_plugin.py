@@ -1,6 +1,7 @@
 """The plugin surface on the GPU: Serra09.similarity / all_pairwise / getEvalStatistics against the
 reference's own scores for the covers80-shaped corpus (BASELINE config 0/1) and against the oracle
 for file-based features."""
+import os
 import zlib
 
 import numpy as np
@@ -131,3 +132,19 @@ def test_mixed_size_batch_splits_by_size_class(orc):
     for t, (i, j) in enumerate(pairs):
         q, d = orc.serra09_pair(ch.song(i), ch.gchroma[i], ch.song(j), ch.gchroma[j])
         assert got["qmax"][t] == q and got["dmax"][t] == d, (t, i, j)
+
+
+def test_randomised_ragged_pairs_against_oracle(orc):
+    """4000 random pairs (both orientations) of a 350-song corpus with lengths 60..1032: the product chain's qmax and dmax
+    equal the oracle's exactly (tools/soak.py runs the same check on 30 000 pairs)."""
+    from acoss_amd import engine, synth
+    engine.require_gpu()
+    rng = np.random.default_rng(3)
+    ch = synth.make_corpus(40, 8, seed=3, singletons=30, lengths=lambda r: int(np.clip(r.normal(520, 160), 60, 1032)))
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    allp = synth.all_pairs(ch.n_songs)
+    pairs = allp[rng.permutation(len(allp))[:4000]]
+    pairs = np.where(rng.random((len(pairs), 1)) < 0.5, pairs, pairs[:, ::-1]).astype(np.int32)
+    got = engine.serra09_scores(corpus, pairs)
+    q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=min(os.cpu_count() or 1, 16))
+    assert np.array_equal(got["qmax"], q) and np.array_equal(got["dmax"], d)
