@@ -68,6 +68,7 @@ SIGNATURES = {
     "acoss_binarize_work_bytes": (_sz, [_i, _i, _i, _i]),
     "acoss_binarize_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
     "acoss_align_bits_qd_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "acoss_mask_bits_words": (_i, [_i, _i, _i]),
     "acoss_mask_bits_work_bytes": (_sz, [_i, _i, _i, _i]),
     "acoss_mask_bits_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
     "acoss_mask_bits_planar_batch": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),

@@ -680,11 +680,11 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc
     const int i = ri * 64 + lane;
     uint64_t rw = 0;
     if (i < M && cw * 64 < N) {
-        rw = w.row_bits[((int64_t)p * w.max_m + i) * 16 + cw];
+        rw = w.row_bits[((int64_t)p * w.max_m + i) * w.wpr + cw];
     }
     if (mutual) {
         const int j = cw * 64 + lane;
-        const uint64_t cwd = j < N ? w.col_bits[((int64_t)p * w.max_n + j) * 16 + ri] : 0ull;
+        const uint64_t cwd = j < N ? w.col_bits[((int64_t)p * w.max_n + j) * w.wpr + ri] : 0ull;
         const unsigned clo = (unsigned)cwd, chi = (unsigned)(cwd >> 32);
         uint64_t tr = 0;
 #pragma unroll
@@ -695,7 +695,108 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc
         }
         rw &= tr;
     }
-    if (i < M) out[((int64_t)p * w.max_m + i) * 16 + cw] = rw;
+    if (i < M) out[((int64_t)p * w.max_m + i) * w.wpr + cw] = rw;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Selection for matrices of any size (beyond 2048 x 2048, where a row no longer fits the registers of one wave):
+// one 256-thread block per row (DIR 0) or column (DIR 1), most-significant-digit-first radix select with 8-bit
+// digits over the order-preserving keys.  The row is read from memory (L2) once per digit and the search stops as
+// soon as the bucket holds a single element; exact ties are cut lowest position first, like every other selection
+// here.  Slow next to the register-resident kernels (a column walk is strided), but correct for every length.
+// ---------------------------------------------------------------------------------------------
+template <int DIR>
+__global__ __launch_bounds__(256) void select_generic_kernel(const double *__restrict__ S,
+                                                             const acoss_pair_desc *__restrict__ descs, int win,
+                                                             double kv, int k_mode, ThreshWork w, int per_pair)
+{
+    __shared__ __attribute__((aligned(16))) unsigned hist[256];
+    __shared__ unsigned long long sh_key;
+    __shared__ int sh_digit, sh_rank, sh_count, sh_cut, sh_wave[4];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / per_pair, which = lb % per_pair;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int count = DIR == 0 ? M : N, len = DIR == 0 ? N : M;
+    if (which >= count) return;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int k = k_mode == 0 ? (int)rint(kv * (double)len) : (k_mode == 1 ? (int)kv : len);
+    uint64_t *thr = DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n;
+    int *cut = DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n;
+    SelectResult res;
+    if (trivial_select(k, len, res)) {
+        if (tid == 0) { thr[which] = res.thr_key; cut[which] = res.cut; }
+        return;
+    }
+    const double *base = S + ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch : (int64_t)which);
+    const int64_t stride = DIR == 0 ? 1 : ds.crp_pitch;
+    uint64_t prefix = 0, mask = 0;
+    int rank = k, bucket = len, shift = 56;
+    for (; shift >= 0; shift -= 8) {
+        hist[tid] = 0;
+        __syncthreads();
+        for (int t = tid; t < len; t += 256) {
+            const uint64_t key = f64_key(base[t * stride]);
+            if ((key & mask) == prefix) atomicAdd(&hist[(unsigned)(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            // lane l owns digits 4l .. 4l+3
+            const uint4 c = reinterpret_cast<const uint4 *>(hist)[lane];
+            const int tot = (int)(c.x + c.y + c.z + c.w);
+            const int incl = wave_scan<OpAdd>(tot, 0);
+            const bool mine = (incl - tot < rank) & (rank <= incl);       // exactly one lane
+            if (mine) {
+                int r = rank - (incl - tot), d = 0, cnt = (int)c.x;
+                if (r > cnt) { r -= cnt; d = 1; cnt = (int)c.y;
+                    if (r > cnt) { r -= cnt; d = 2; cnt = (int)c.z;
+                        if (r > cnt) { r -= cnt; d = 3; cnt = (int)c.w; } } }
+                sh_digit = 4 * lane + d;
+                sh_rank = r;
+                sh_count = cnt;
+            }
+        }
+        __syncthreads();
+        prefix |= (uint64_t)(unsigned)sh_digit << shift;
+        mask |= 255ull << shift;
+        rank = sh_rank;
+        bucket = sh_count;
+        if (bucket == 1) break;
+    }
+    res.cut = 0x7fffffff;
+    if (shift > 0) {
+        // one element left in the bucket: it is the k-th smallest
+        for (int t = tid; t < len; t += 256) {
+            const uint64_t key = f64_key(base[t * stride]);
+            if ((key & mask) == prefix) sh_key = key;
+        }
+        __syncthreads();
+        res.thr_key = sh_key;
+    } else {
+        res.thr_key = prefix;
+        if (bucket > rank) {
+            // `bucket` equal keys, `rank` of them are taken: the rank-th lowest position is the cut
+            int seen = 0;
+            if (tid == 0) sh_cut = 0x7fffffff;
+            for (int c0 = 0; c0 < len && seen < rank; c0 += 256) {
+                const int t = c0 + tid;
+                const bool eq = t < len && f64_key(base[t * stride]) == prefix;
+                const uint64_t bal = __ballot(eq);
+                __syncthreads();
+                if (lane == 0) sh_wave[tid >> 6] = __popcll(bal);
+                __syncthreads();
+                int before = seen;
+                for (int v = 0; v < (tid >> 6); v++) before += sh_wave[v];
+                before += __popcll(bal & ((1ull << lane) - 1ull));
+                if (eq && before + 1 == rank) sh_cut = t;
+                seen += sh_wave[0] + sh_wave[1] + sh_wave[2] + sh_wave[3];
+            }
+            __syncthreads();
+            res.cut = sh_cut;
+        }
+    }
+    if (tid == 0) { thr[which] = res.thr_key; cut[which] = res.cut; }
 }
 
 
@@ -841,7 +942,7 @@ static void kappa_mode(double kappa, double &kv, int &mode)
 // shared with planar_kernels.hip
 int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st)
 {
-    const int tm = ceil_div(w.max_m, 64), tn = 16;     // all 16 words of every row are written
+    const int tm = ceil_div(w.max_m, 64), tn = w.wpr;     // every word of every row is written
     const int64_t waves = (int64_t)K * tm * tn;
     hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, st, descs, K, win, mutual, w, tm, tn, bits);
     return launch_check("combine_bits_kernel");
@@ -961,8 +1062,8 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
         set_error("thresholds: workspace too small");
         return ACOSS_EINVAL;
     }
-    if (max_m > 2048 || max_n > 2048 || (with_bits && (max_m > 1024 || max_n > 1024))) {
-        set_error("thresholds: matrices larger than 2048 x 2048 (1024 x 1024 for bit masks) are not supported yet");
+    if (with_bits && (max_m > 1024 || max_n > 1024)) {
+        set_error("mask_bits: matrices larger than 1024 x 1024 are not supported (acoss_mask_bits_planar_batch goes to 2048)");
         return ACOSS_ENOTSUP;
     }
     w = thresh_work_layout(work, K, max_m, max_n, with_bits);
@@ -972,7 +1073,10 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
     kappa_mode(kappa, kv, mode);
     {
         const int rb = ceil_div(max_m, 4 * SEL_ROWS_PER_WAVE);
-        if (max_n <= 1024)
+        if (max_n > 2048) {
+            if ((int64_t)K * max_m > 0x7fffffffLL) { set_error("thresholds: batch too large"); return ACOSS_ENOTSUP; }
+            hipLaunchKernelGGL(select_generic_kernel<0>, dim3((unsigned)((int64_t)K * max_m)), dim3(256), 0, st, S, descs, win, kv, mode, w, max_m);
+        } else if (max_n <= 1024)
             hipLaunchKernelGGL((select_rows_kernel<16>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
         else
             hipLaunchKernelGGL((select_rows_kernel<32>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, S, descs, win, kv, mode, w, rb);
@@ -987,7 +1091,10 @@ static int run_thresholds(const double *S, const acoss_pair_desc *descs, int K, 
     }
     if (mutual) {
         const int cb = ceil_div(max_n, SEL_COLS_PER_BLOCK);
-        if (max_m <= 1024) {
+        if (max_m > 2048) {
+            if ((int64_t)K * max_n > 0x7fffffffLL) { set_error("thresholds: batch too large"); return ACOSS_ENOTSUP; }
+            hipLaunchKernelGGL(select_generic_kernel<1>, dim3((unsigned)((int64_t)K * max_n)), dim3(256), 0, st, S, descs, win, kv, mode, w, max_n);
+        } else if (max_m <= 1024) {
             const size_t lds = sizeof(double) * SEL_COLS_PER_BLOCK * (16 * 64 + 2);
             ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(select_cols_kernel<16>, dim3((unsigned)((int64_t)K * cb)), dim3(SEL_COLS_THREADS), lds, st, S, descs, win, kv, mode, w, cb);
@@ -1013,6 +1120,11 @@ int acoss_thresholds_batch(const double *S, const acoss_pair_desc *descs, int K,
 {
     ThreshWork w;
     return run_thresholds(S, descs, K, win, max_nx, max_ny, kappa, mutual, work, work_bytes, (hipStream_t)stream, w);
+}
+
+int acoss_mask_bits_words(int max_nx, int max_ny, int win)
+{
+    return mask_bits_words(max_nx - win + 1, max_ny - win + 1);
 }
 
 size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win)

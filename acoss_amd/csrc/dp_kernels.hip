@@ -521,17 +521,23 @@ __global__ __launch_bounds__(256, 2) void dp_fused_kernel(const double *__restri
 // With ~60 VGPRs eight such waves share a SIMD, and a pair's whole mask is 124 KB: this sweep costs a
 // fraction of the selection passes.  Constant gap penalty, <= 1024 columns.
 // ---------------------------------------------------------------------------------------------
-template <int KIND>
+// the mask bits of a lane's CPL columns in one row: a uint16 / uint32 load; `ext` holds them shifted left by two
+template <int CPL> struct BitsRow;
+template <> struct BitsRow<16> { using type = unsigned short; using ext = unsigned; };
+template <> struct BitsRow<32> { using type = unsigned; using ext = uint64_t; };
+
+template <int KIND, int CPL>
 __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict__ bits,
                                                       const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                       int max_m, float gamma, int boundary, float4 sw,
                                                       float *__restrict__ scores)
 {
     // sw = (match, mismatch, gap open, gap extension) of swalignimpconstrained (SequenceAlignment.c:43-63)
-    constexpr int CPL = 16;
+    using row_t = typename BitsRow<CPL>::type;
+    using ext_t = typename BitsRow<CPL>::ext;
     constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
     constexpr int R0 = (KIND == KIND_DMAX) ? 1 : 2;
-    constexpr int PF = 16;
+    constexpr int PF = CPL == 16 ? 16 : 8;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.x * 4 + wave;
     if (p >= K) return;
@@ -543,7 +549,7 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
         return;
     }
     const int j0 = lane * CPL;
-    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    const row_t *rowp = reinterpret_cast<const row_t *>(bits + (int64_t)p * max_m * CPL) + lane;
     unsigned ring[PF];
 #pragma unroll
     for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(R0 + u, M - 1) * 64];
@@ -564,11 +570,11 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
                 h3a = lane_shr1(d3[CPL - 1], 0.f);
                 h0 = (unsigned)lane_shr1((int)m0, 0);
             }
-            const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);
-            unsigned ext1 = 0, ext2 = 0;            // rows i-1, i-2 shifted so that bit c+2 = column c (KIND_SWC)
+            const ext_t ext = ((ext_t)m0 << 2) | ((h0 >> (CPL - 2)) & 3u);
+            ext_t ext1 = 0, ext2 = 0;            // rows i-1, i-2 shifted so that bit c+2 = column c (KIND_SWC)
             if (KIND == KIND_SWC) {
-                ext1 = (m1 << 2) | (((unsigned)lane_shr1((int)m1, 0) >> 14) & 3u);
-                ext2 = (m2 << 2) | (((unsigned)lane_shr1((int)m2, 0) >> 14) & 3u);
+                ext1 = ((ext_t)m1 << 2) | (((unsigned)lane_shr1((int)m1, 0) >> (CPL - 2)) & 3u);
+                ext2 = ((ext_t)m2 << 2) | (((unsigned)lane_shr1((int)m2, 0) >> (CPL - 2)) & 3u);
             }
             float nd[CPL];
 #pragma unroll
@@ -582,8 +588,8 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
                     const float p_left3 = c >= 3 ? d1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));
                     const float s_u1 = (float)((m1 >> c) & 1u);
                     const float s_u2 = (float)((m2 >> c) & 1u);
-                    const float s_l1 = (float)((ext >> (c + 1)) & 1u);
-                    const float s_l2 = (float)((ext >> c) & 1u);
+                    const float s_l1 = (float)((unsigned)(ext >> (c + 1)) & 1u);
+                    const float s_l2 = (float)((unsigned)(ext >> c) & 1u);
                     const float c2 = p_up2 + s_u1;
                     const float c3 = p_left2 + s_l1;
                     const float c4 = (p_up3 + s_u2) + s_u1;
@@ -595,9 +601,9 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
                 if (KIND == KIND_SWC) {
                     // same expression order as dp_wave_kernel<KIND_SWC> (the -0.7 penalty is inexact in float32)
                     const float ms = on ? sw.x : sw.y;
-                    const float e1 = on ? 0.0f : (((ext1 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-1][b-1]
-                    const float e2 = on ? 0.0f : (((ext2 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-2][b-1]
-                    const float e3 = on ? 0.0f : (((ext1 >> c) & 1u) ? sw.z : sw.w);           // S[a-1][b-2]
+                    const float e1 = on ? 0.0f : (((unsigned)(ext1 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-1][b-1]
+                    const float e2 = on ? 0.0f : (((unsigned)(ext2 >> (c + 1)) & 1u) ? sw.z : sw.w);     // S[a-2][b-1]
+                    const float e3 = on ? 0.0f : (((unsigned)(ext1 >> c) & 1u) ? sw.z : sw.w);           // S[a-1][b-2]
                     v = fmaxf(max3f((p_diag + ms) + e1, (p_up2 + ms) + e2, (p_left2 + ms) + e3), 0.0f);
                 }
                 if (c < FIRST) {
@@ -638,12 +644,15 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
 // that qmax leaves behind = `boundary`): the two recurrences are independent given the mask rows, so their
 // dependent chains interleave in one instruction stream and the mask is read once.  Same arithmetic per kind as
 // dp_bits_kernel.
+template <int CPL>
 __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restrict__ bits,
                                                          const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                          int max_m, float gamma, int boundary,
                                                          float *__restrict__ qscores, float *__restrict__ dscores)
 {
-    constexpr int CPL = 16, PF = 16;
+    using row_t = typename BitsRow<CPL>::type;
+    using ext_t = typename BitsRow<CPL>::ext;
+    constexpr int PF = CPL == 16 ? 16 : 8;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.x * 4 + wave;
     if (p >= K) return;
@@ -656,7 +665,7 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
         return;
     }
     const int j0 = lane * CPL;
-    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    const row_t *rowp = reinterpret_cast<const row_t *>(bits + (int64_t)p * max_m * CPL) + lane;
     unsigned ring[PF];
 #pragma unroll
     for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(1 + u, M - 1) * 64];
@@ -694,7 +703,7 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
                 const float h1a = lane_shr1(e1[CPL - 1], 0.f), h1b = lane_shr1(e1[CPL - 2], 0.f), h1c = lane_shr1(e1[CPL - 3], 0.f);
                 const float h2a = lane_shr1(e2[CPL - 1], 0.f), h3a = lane_shr1(e3[CPL - 1], 0.f);
                 const unsigned h0 = (unsigned)lane_shr1((int)m0, 0);
-                const unsigned ext = (m0 << 2) | ((h0 >> 14) & 3u);
+                const ext_t ext = ((ext_t)m0 << 2) | ((h0 >> (CPL - 2)) & 3u);
                 float nd[CPL];
 #pragma unroll
                 for (int c = 0; c < CPL; c++) {
@@ -705,8 +714,8 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
                     const float p_left3 = c >= 3 ? e1[c - 3] : (c == 2 ? h1a : (c == 1 ? h1b : h1c));
                     const float s_u1 = (float)((m1 >> c) & 1u);
                     const float s_u2 = (float)((m2 >> c) & 1u);
-                    const float s_l1 = (float)((ext >> (c + 1)) & 1u);
-                    const float s_l2 = (float)((ext >> c) & 1u);
+                    const float s_l1 = (float)((unsigned)(ext >> (c + 1)) & 1u);
+                    const float s_l2 = (float)((unsigned)(ext >> c) & 1u);
                     const float c2 = p_up2 + s_u1;
                     const float c3 = p_left2 + s_l1;
                     const float c4 = (p_up3 + s_u2) + s_u1;
@@ -814,19 +823,29 @@ int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     acoss_align_params ap;
     if (params) ap = *params; else acoss_default_align_params(&ap);
-    if (max_n > 1024 || max_m > 1024 || ap.gamma_onset != ap.gamma_extension) {
-        set_error("align_bits_batch: needs <= 1024 x 1024 matrices and gamma_onset == gamma_extension");
+    if (max_n > 2048 || max_m > 2048 || ap.gamma_onset != ap.gamma_extension) {
+        set_error("align_bits_batch: needs <= 2048 x 2048 matrices and gamma_onset == gamma_extension");
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
     hipStream_t st = (hipStream_t)stream;
     const float4 sw = make_float4(ap.sw_match, ap.sw_mismatch, ap.sw_gap_open, ap.sw_gap_ext);
-    if (kind == 0)
-        hipLaunchKernelGGL(dp_bits_kernel<KIND_QMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
-    else if (kind == 1)
-        hipLaunchKernelGGL(dp_bits_kernel<KIND_DMAX>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, sw, scores);
-    else
-        hipLaunchKernelGGL(dp_bits_kernel<KIND_SWC>, dim3(ceil_div(K, 4)), dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+    const dim3 grid(ceil_div(K, 4));
+    if (mask_bits_words(max_m, max_n) == 16) {
+        if (kind == 0)
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_QMAX, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+        else if (kind == 1)
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_DMAX, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, sw, scores);
+        else
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_SWC, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+    } else {
+        if (kind == 0)
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_QMAX, 32>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+        else if (kind == 1)
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_DMAX, 32>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, sw, scores);
+        else
+            hipLaunchKernelGGL((dp_bits_kernel<KIND_SWC, 32>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
+    }
     return launch_check("dp_bits_kernel");
 }
 
@@ -841,13 +860,17 @@ int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     acoss_align_params ap;
     if (params) ap = *params; else acoss_default_align_params(&ap);
-    if (max_n > 1024 || max_m > 1024 || ap.gamma_onset != ap.gamma_extension) {
-        set_error("align_bits_qd_batch: needs <= 1024 x 1024 matrices and gamma_onset == gamma_extension");
+    if (max_n > 2048 || max_m > 2048 || ap.gamma_onset != ap.gamma_extension) {
+        set_error("align_bits_qd_batch: needs <= 2048 x 2048 matrices and gamma_onset == gamma_extension");
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
-    hipLaunchKernelGGL(dp_bits_qd_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m,
-                       ap.gamma_onset, boundary, qmax_scores, dmax_scores);
+    if (mask_bits_words(max_m, max_n) == 16)
+        hipLaunchKernelGGL(dp_bits_qd_kernel<16>, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m,
+                           ap.gamma_onset, boundary, qmax_scores, dmax_scores);
+    else
+        hipLaunchKernelGGL(dp_bits_qd_kernel<32>, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m,
+                           ap.gamma_onset, boundary, qmax_scores, dmax_scores);
     return launch_check("dp_bits_qd_kernel");
 }
 

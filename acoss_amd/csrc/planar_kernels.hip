@@ -27,34 +27,39 @@ __device__ inline void planar_put_lane_u64(unsigned &lo, unsigned &hi, uint64_t 
         : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(e));
 }
 
-// lane e (< 16) = lane mask of "position e*64 + lane exists"
+// lane e (< E) = lane mask of "position e*64 + lane exists"
+template <int E>
 __device__ inline uint64_t planar_slot_valid(int n, int lane)
 {
     unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int e = 0; e < 16; e++) planar_put_lane_u64(lo, hi, __ballot(e * 64 + lane < n), e);
+    for (int e = 0; e < E; e++) planar_put_lane_u64(lo, hi, __ballot(e * 64 + lane < n), e);
     return ((uint64_t)hi << 32) | lo;
 }
 
 // word e of out = lanes whose element e is selected (high word <= the threshold's), positions e*64 + lane
-__device__ inline void planar_emit_bits(const unsigned (&h)[16], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane)
+template <int E>
+__device__ inline void planar_emit_bits(const unsigned (&h)[E], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane)
 {
     unsigned lo = 0, hi = 0;
 #pragma unroll
-    for (int e = 0; e < 16; e++) planar_put_lane_u64(lo, hi, __ballot(h[e] <= thr_hi), e);
-    if (lane < 16) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
+    for (int e = 0; e < E; e++) planar_put_lane_u64(lo, hi, __ballot(h[e] <= thr_hi), e);
+    if (lane < E) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
 }
 
 // k-th smallest of the n high words a wave holds (h[e] = position e*64 + lane; positions >= n repeat a real
 // element and are ignored), by the histogram method of wave_select16_hist (wave_ops.h).  Returns the winning
 // high word with cut = INT_MAX when no other element shares it, else cut = SELECT_UNRESOLVED.
-__device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], int n, int k, unsigned *hist, int lane,
-                                                      HistWarm &warm)
+// E = 16 (<= 1024 elements) or 32 (<= 2048; the bin numbers are recomputed instead of held in registers).
+template <int E>
+__device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int n, int k, unsigned *hist, int lane,
+                                                    HistWarm &warm)
 {
+    constexpr bool KEEP = E <= 16;
     SelectResult res;
     res.thr_key = 0;
     res.cut = SELECT_UNRESOLVED;
-    unsigned bin[16];
+    unsigned bin[KEEP ? E : 1];
     enum { PREDICTED, FULL, REFINE };
     int kind = warm.hi != 0 ? PREDICTED : FULL;
     unsigned lo = 0;
@@ -71,7 +76,7 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
         if (kind == FULL) {
             unsigned mn = 0xffffffffu, mx = 0u;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
+            for (int e = 0; e < E; e++) {
                 mn = min(mn, h[e]);
                 mx = max(mx, h[e]);
             }
@@ -81,15 +86,16 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
             shift = max(0, 32 - (int)__clz(mx - mn) - HIST_LOG2);
         } else {
 #pragma unroll
-            for (int e = 0; e < 16; e++) below += __popcll(__ballot((h[e] < lo) & (e * 64 + lane < n)));
+            for (int e = 0; e < E; e++) below += __popcll(__ballot((h[e] < lo) & (e * 64 + lane < n)));
         }
         const unsigned spill = (unsigned)(HIST_BINS + lane);
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
+        for (int e = 0; e < E; e++) {
             unsigned b = min((h[e] - lo) >> shift, spill);
             asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
-            bin[e] = e * 64 + lane < n ? b : spill;
-            atomicAdd(&hist[bin[e]], 1u);
+            b = e * 64 + lane < n ? b : spill;
+            if constexpr (KEEP) bin[e] = b;
+            atomicAdd(&hist[b], 1u);
         }
         const int kk = k - below;
         uint4 c4[HIST_BPL / 4];
@@ -121,8 +127,10 @@ __device__ inline SelectResult wave_select16_hist_u32(const unsigned (&h)[16], i
         uint64_t dup = 0;
         any = 0;
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
-            const bool in = bin[e] == bstar;
+        for (int e = 0; e < E; e++) {
+            bool in;
+            if constexpr (KEEP) in = bin[e] == bstar;
+            else in = (((h[e] - lo) >> shift) == bstar) & (h[e] >= lo) & (e * 64 + lane < n);
             const uint64_t m = __ballot(in);
             dup |= any & m;
             any |= m;
@@ -183,8 +191,8 @@ __device__ inline int knn_count(int k_mode, double kv, int len)
 constexpr int PL_ROWS_PER_WAVE = 8;
 
 // MODE (development probes): 1 = loads only
-template <int MODE = 0>
-__global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32_t *__restrict__ Thi,
+template <int MODE = 0, int E = 16>
+__global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kernel(const uint32_t *__restrict__ Thi,
                                                                    const acoss_pair_desc *__restrict__ descs, int win,
                                                                    double kv, int k_mode, ThreshWork w, int rows_blocks)
 {
@@ -204,16 +212,16 @@ __global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32
     unsigned *hist = hist_all + wave * HIST_WORDS;
     hist_clear(hist, lane);
     HistWarm warm{0, HIST_WARM_SHIFT0};
-    const uint64_t valid = planar_slot_valid(N, lane);
-    const bool wide = N > 15 * 64;       // wave-uniform: only the last slot can run past the row
+    const uint64_t valid = planar_slot_valid<E>(N, lane);
+    const bool wide = N > (E - 1) * 64;       // wave-uniform: only the last slot can run past the row
     for (int i = r0; i < r1; i++) {
         const uint32_t *row = Thi + ds.crp_off + (int64_t)i * ds.crp_pitch;
-        unsigned h[16];
+        unsigned h[E];
         if (wide) {
             // wave-uniform row pointer + one lane offset + immediates: 256 contiguous bytes per load instruction
 #pragma unroll
-            for (int e = 0; e < 15; e++) h[e] = row[(unsigned)(e * 64 + lane)];
-            h[15] = row[(unsigned)min(15 * 64 + lane, N - 1)];
+            for (int e = 0; e < E - 1; e++) h[e] = row[(unsigned)(e * 64 + lane)];
+            h[E - 1] = row[(unsigned)min((E - 1) * 64 + lane, N - 1)];
         } else {
             // (cold path: the lane number is laundered through an empty asm so that the sixteen clamped offsets are
             // computed here instead of being hoisted in front of the row loop, where they would set the register
@@ -221,24 +229,24 @@ __global__ __launch_bounds__(256, 6) void select_rows_planar_kernel(const uint32
             int lc = lane;
             asm volatile("" : "+v"(lc));
 #pragma unroll
-            for (int e = 0; e < 16; e++) h[e] = row[(unsigned)min(e * 64 + lc, N - 1)];
+            for (int e = 0; e < E; e++) h[e] = row[(unsigned)min(e * 64 + lc, N - 1)];
         }
         if constexpr (MODE == 1) {
             unsigned acc = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) acc += h[e];
+            for (int e = 0; e < E; e++) acc += h[e];
             if (acc == 0x12345u) thr[i] = 0;
             continue;
         }
         SelectResult res;
-        if (!planar_trivial(k, N, res)) res = wave_select16_hist_u32(h, N, k, hist, lane, warm);
+        if (!planar_trivial(k, N, res)) res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
         if (lane == 0) {
             thr[i] = res.thr_key;
             cut[i] = res.cut;
         }
         if (w.row_bits && res.cut != SELECT_UNRESOLVED)
-            planar_emit_bits(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
-                             w.row_bits + ((int64_t)p * w.max_m + i) * 16, lane);
+            planar_emit_bits<E>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
+                                w.row_bits + ((int64_t)p * w.max_m + i) * E, lane);
     }
 }
 
@@ -311,22 +319,92 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     unsigned *hist = pcolbuf + (2 * wave) * PL_LDC;      // 2 * PL_LDC words >= HIST_WORDS, 16-byte aligned
     hist_clear(hist, lane);
     const int k = knn_count(k_mode, kv, M);
-    const uint64_t valid = planar_slot_valid(M, lane);
+    const uint64_t valid = planar_slot_valid<16>(M, lane);
     HistWarm warm{0, HIST_WARM_SHIFT0};
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
-        else if (!planar_trivial(k, M, res)) res = wave_select16_hist_u32(h, M, k, hist, lane, warm);
+        else if (!planar_trivial(k, M, res)) res = wave_select_hist_u32<16>(h, M, k, hist, lane, warm);
         if (lane == 0) {
             w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
             w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
         }
         if (w.col_bits && res.cut != SELECT_UNRESOLVED)
-            planar_emit_bits(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
-                             w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+            planar_emit_bits<16>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
+                                 w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
     };
     column(ha, ja);
     if (ja + 1 < N) column(hb, ja + 1);
+}
+
+// Columns of matrices with up to 2048 rows: COLS waves, one column each (32 values per lane), the block's
+// columns staged whole (8 columns = 66 KB of LDS: two blocks per CU, one loading while the other selects).
+// Same selection and outputs as above.
+constexpr int PLW_LDC = 2048 + 4;
+
+template <int COLS>
+__global__ __launch_bounds__(64 * COLS) void select_cols_planar_wide_kernel(const uint32_t *__restrict__ Thi,
+                                                                      const acoss_pair_desc *__restrict__ descs, int win,
+                                                                      double kv, int k_mode, ThreshWork w, int col_blocks)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned pcolbuf[];      // [COLS][PLW_LDC]
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / col_blocks;
+    const int j0 = (lb % col_blocks) * COLS;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (j0 >= N) return;
+    {
+        // 128 rows x COLS / 2 column pairs per sweep, 16 sweeps (M <= 2048); sweeps past the last row are skipped
+        const int c2 = threadIdx.x & (COLS / 2 - 1), rr = threadIdx.x / (COLS / 2);
+        const bool fast = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0) && (j0 + COLS <= N);
+        const int sweeps = (M + 127) >> 7;
+        const uint32_t *pb = Thi + ds.crp_off + j0 + 2 * c2;        // (fast) block-uniform base + 32-bit word offsets
+        uint2 tmp[16];
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            if (s < sweeps) {          // block-uniform: no loads for sweeps past the last row
+                const int row = min(s * 128 + rr, M - 1);
+                if (fast) {
+                    tmp[s] = *reinterpret_cast<const uint2 *>(pb + (unsigned)(row * ds.crp_pitch));
+                } else {
+                    const int64_t ri = ds.crp_off + (int64_t)row * ds.crp_pitch;
+                    tmp[s].x = Thi[ri + min(j0 + 2 * c2 + 0, N - 1)];
+                    tmp[s].y = Thi[ri + min(j0 + 2 * c2 + 1, N - 1)];
+                }
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 16; s++) {
+            if (s < sweeps) {
+                unsigned *dst = pcolbuf + (2 * c2) * PLW_LDC + s * 128 + rr;
+                dst[0 * PLW_LDC] = tmp[s].x;
+                dst[1 * PLW_LDC] = tmp[s].y;
+            }
+        }
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int j = j0 + wave;
+    if (j >= N) return;
+    unsigned h[32];
+#pragma unroll
+    for (int e = 0; e < 32; e++) h[e] = pcolbuf[wave * PLW_LDC + min(e * 64 + lane, M - 1)];
+    unsigned *hist = pcolbuf + wave * PLW_LDC;      // the wave's own column slot: PLW_LDC words >= HIST_WORDS
+    hist_clear(hist, lane);
+    const int k = knn_count(k_mode, kv, M);
+    const uint64_t valid = planar_slot_valid<32>(M, lane);
+    HistWarm warm{0, HIST_WARM_SHIFT0};
+    SelectResult res;
+    if (!planar_trivial(k, M, res)) res = wave_select_hist_u32<32>(h, M, k, hist, lane, warm);
+    if (lane == 0) {
+        w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
+        w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
+    }
+    if (w.col_bits && res.cut != SELECT_UNRESOLVED)
+        planar_emit_bits<32>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
+                             w.col_bits + ((int64_t)p * w.max_n + j) * 32, lane);
 }
 
 // ---- fix-up: rows / columns whose winner shares its high word -----------------------------------------------
@@ -350,7 +428,7 @@ __device__ inline double planar_exact_value(const double *__restrict__ feats, co
     return s;
 }
 
-template <int DIR>
+template <int DIR, int E = 16>
 __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
                                                                const double *__restrict__ norms, int d,
                                                                const acoss_pair_desc *__restrict__ descs, int win,
@@ -374,10 +452,10 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
         // the selection kernel left the high word the tied elements share: only those few need their exact value;
         // every other element is ordered by its high word alone
         const unsigned th = (unsigned)(thr[which] >> 32);
-        uint64_t key[16];
-        int idx[16];
+        uint64_t key[E];
+        int idx[E];
 #pragma unroll
-        for (int e = 0; e < 16; e++) {
+        for (int e = 0; e < E; e++) {
             idx[e] = e * 64 + lane;
             const int q = min(idx[e], len - 1);
             const unsigned h = Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
@@ -387,22 +465,22 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
                                       : planar_exact_value(feats, norms, d, ds, win, q, which));
             key[e] = idx[e] < len ? kx : ~0ull;
         }
-        const SelectResult res = wave_select_kth<16>(key, idx, len, k);
+        const SelectResult res = wave_select_kth<E>(key, idx, len, k);
         if (lane == 0) {
             thr[which] = res.thr_key;
             cut[which] = res.cut;
         }
         uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
         if (bits) {
-            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * 16;
+            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * E;
             uint64_t mine = 0;
 #pragma unroll
-            for (int e = 0; e < 16; e++) {
+            for (int e = 0; e < E; e++) {
                 const bool on = (idx[e] < len) & ((key[e] < res.thr_key) | ((key[e] == res.thr_key) & (idx[e] <= res.cut)));
                 const uint64_t m = __ballot(on);
                 if (lane == e) mine = m;
             }
-            if (lane < 16) bits[lane] = mine;
+            if (lane < E) bits[lane] = mine;
         }
     }
 }
@@ -427,8 +505,8 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         return ACOSS_EINVAL;
     }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    if (max_m > 1024 || max_n > 1024) {
-        set_error("mask_bits_planar: matrices larger than 1024 x 1024 are not supported");
+    if (max_m > 2048 || max_n > 2048) {
+        set_error("mask_bits_planar: matrices larger than 2048 x 2048 are not supported");
         return ACOSS_ENOTSUP;
     }
     if (work_bytes < thresh_work_bytes(K, max_m, max_n, true)) {
@@ -444,6 +522,30 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
     const int cb = ceil_div(max_n, PL_COLS);
     const size_t lds = sizeof(unsigned) * PL_COLS * PL_LDC;
     if ((int64_t)K * rb > 0x7fffffffLL || (int64_t)K * cb > 0x7fffffffLL) { set_error("mask_bits_planar: batch too large"); return ACOSS_ENOTSUP; }
+    if (w.wpr == 32) {
+        // up to 2048 x 2048: 32 values per lane, one column per wave (the probes are for the 16-word kernels)
+        if (probe != 0) { set_error("mask_bits_planar: no probes for matrices beyond 1024 x 1024"); return ACOSS_ENOTSUP; }
+        hipLaunchKernelGGL((select_rows_planar_kernel<0, 32>), dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
+        int rc = launch_check("select_rows_planar_kernel<32>");
+        if (rc) return rc;
+        const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
+        hipLaunchKernelGGL((select_fix_planar_kernel<0, 32>), dim3((unsigned)((int64_t)K * gm)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gm);
+        rc = launch_check("select_fix_planar_kernel<rows, 32>");
+        if (rc) return rc;
+        if (mutual) {
+            constexpr int WC = 8;
+            const int cbw = ceil_div(max_n, WC);
+            const size_t ldw = sizeof(unsigned) * WC * PLW_LDC;
+            ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_wide_kernel<WC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldw));
+            hipLaunchKernelGGL(select_cols_planar_wide_kernel<WC>, dim3((unsigned)((int64_t)K * cbw)), dim3(64 * WC), ldw, st, planes, descs, win, kv, mode, w, cbw);
+            rc = launch_check("select_cols_planar_wide_kernel");
+            if (rc) return rc;
+            hipLaunchKernelGGL((select_fix_planar_kernel<1, 32>), dim3((unsigned)((int64_t)K * gn)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gn);
+            rc = launch_check("select_fix_planar_kernel<cols, 32>");
+            if (rc) return rc;
+        }
+        return launch_combine_bits(descs, K, win, mutual, w, bits, st);
+    }
     if (probe == 1) {
         hipLaunchKernelGGL(select_rows_planar_kernel<1>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
         return launch_check("select_rows_planar probe");

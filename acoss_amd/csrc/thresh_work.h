@@ -14,16 +14,20 @@ struct ThreshWork {
     int *row_cut;        // [K][max_m]
     int *col_cut;        // [K][max_n]
     int max_m, max_n;
-    // optional (bit-mask path, <= 1024 x 1024): the selected positions of every row / column, 16 x uint64 each
-    // in the producing kernel's register-slot order (see emit_select_bits)
-    uint64_t *row_bits;  // [K][max_m][16]
-    uint64_t *col_bits;  // [K][max_n][16]
+    // optional (bit-mask path): the selected positions of every row / column, wpr x uint64 each (bit l of word e =
+    // position 64 e + l); wpr = mask_bits_words(max_m, max_n)
+    uint64_t *row_bits;  // [K][max_m][wpr]
+    uint64_t *col_bits;  // [K][max_n][wpr]
+    int wpr;
 };
+
+// uint64 words per row of the bit planes and of the bit-packed mask: 16 up to 1024 x 1024, 32 up to 2048 x 2048
+inline int mask_bits_words(int max_m, int max_n) { return (max_m > 1024 || max_n > 1024) ? 32 : 16; }
 
 inline size_t thresh_work_bytes(int K, int max_m, int max_n, bool with_bits)
 {
     size_t b = (size_t)K * (size_t)(max_m + max_n) * (sizeof(uint64_t) + sizeof(int)) + 64;
-    if (with_bits) b += (size_t)K * (size_t)(max_m + max_n) * 16 * sizeof(uint64_t) + 64;
+    if (with_bits) b += (size_t)K * (size_t)(max_m + max_n) * mask_bits_words(max_m, max_n) * sizeof(uint64_t) + 64;
     return b;
 }
 
@@ -38,11 +42,12 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
     w.col_cut = w.row_cut + (size_t)K * max_m;
     w.row_bits = nullptr;
     w.col_bits = nullptr;
+    w.wpr = mask_bits_words(max_m, max_n);
     if (with_bits) {
         uintptr_t a = (uintptr_t)(w.col_cut + (size_t)K * max_n);
         a = (a + 63) & ~(uintptr_t)63;
         w.row_bits = (uint64_t *)a;
-        w.col_bits = w.row_bits + (size_t)K * max_m * 16;
+        w.col_bits = w.row_bits + (size_t)K * max_m * w.wpr;
     }
     return w;
 }

@@ -217,8 +217,14 @@ PLANAR_PITCH_ALIGN = 32     # PairBatch(pitch_align=...) of the fast path: rows 
 
 
 def planar_supported(corpus, batch):
+    """The fast path: float64 chroma / MFCC-sized features, the reference's window, matrices up to 2048 x 2048."""
     return (corpus.dtype == np.float64 and corpus.d in (12, 13) and batch.win == 9
-            and bits_path_supported(batch))
+            and batch.max_nx - batch.win + 1 <= 2048 and batch.max_ny - batch.win + 1 <= 2048)
+
+
+def bits_words(batch):
+    """uint64 words per row of the bit-packed mask of this batch (16 up to 1024 x 1024, else 32)."""
+    return int(_lib.load().acoss_mask_bits_words(batch.max_nx, batch.max_ny, batch.win))
 
 
 def crp_supported(corpus, win):
@@ -275,11 +281,11 @@ def align_fused(kind, T_buf, batch, work, mutual=True, boundary=0, params=None, 
 
 
 def mask_bits(S_buf, batch, kappa, mutual=True, out=None, work=None):
-    """Bit-packed kNN mask of every pair ((K, max_m, 16) uint64; bit c of word w = column 64w + c)."""
+    """Bit-packed kNN mask of every pair ((K, max_m, bits_words) uint64; bit c of word w = column 64w + c)."""
     lib = _lib.load()
     max_m = batch.max_nx - batch.win + 1
     if out is None:
-        out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=S_buf.device)
+        out = torch.zeros(max(batch.K * max_m * bits_words(batch), 1), dtype=torch.int64, device=S_buf.device)
     need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
     if work is None or work.numel() < need:
         work = torch.empty(need, dtype=torch.uint8, device=S_buf.device)
@@ -295,7 +301,7 @@ def mask_bits_planar(planes, corpus, batch, kappa, mutual=True, out=None, work=N
     lib = _lib.load()
     max_m = batch.max_nx - batch.win + 1
     if out is None:
-        out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=planes.device)
+        out = torch.zeros(max(batch.K * max_m * bits_words(batch), 1), dtype=torch.int64, device=planes.device)
     need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
     if work is None or work.numel() < need:
         work = torch.empty(need, dtype=torch.uint8, device=planes.device)
@@ -337,8 +343,9 @@ def unpack_mask_bits(bits, batch, p):
     """Host uint8 (M, N) view of pair p's bit-packed mask (tests)."""
     max_m = batch.max_nx - batch.win + 1
     M, N = int(batch.M[p]), int(batch.N[p])
-    words = bits[p * max_m * 16:(p * max_m + M) * 16].cpu().numpy().view(np.uint64).reshape(M, 16)
-    b = np.unpackbits(words.view(np.uint8).reshape(M, 128), axis=1, bitorder="little")
+    W = bits_words(batch)
+    words = bits[p * max_m * W:(p * max_m + M) * W].cpu().numpy().view(np.uint64).reshape(M, W)
+    b = np.unpackbits(words.view(np.uint8).reshape(M, 8 * W), axis=1, bitorder="little")
     return b[:, :N]
 
 
@@ -415,12 +422,15 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     out = {k: np.zeros(K) for k in want}
     if K == 0:
         return out
-    # pairs whose matrices fit the bit-mask kernels (<= 1024 x 1024) and the few that do not go through separate
-    # batches, so that one long song does not push a whole batch onto the byte-mask path
+    # size classes go through separate batches: matrices up to 1024 x 1024 (16 values per lane in the selection and
+    # alignment kernels), up to 2048 x 2048 (32 per lane), and beyond (byte-mask path), so that one long song does not
+    # push a whole batch onto the slower kernels
     lens = corpus.lengths()
-    big = np.maximum(lens[pairs[:, 0]], lens[pairs[:, 1]]) - m + 1 > 1024
-    if big.any() and not big.all():
-        for part in (np.flatnonzero(~big), np.flatnonzero(big)):
+    side = np.maximum(lens[pairs[:, 0]], lens[pairs[:, 1]]) - m + 1
+    cls = (side > 1024).astype(np.int8) + (side > 2048)
+    if cls.min() != cls.max():
+        for c in np.unique(cls):
+            part = np.flatnonzero(cls == c)
             res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs)
             for k in want:
                 out[k][part] = res[k]
@@ -442,11 +452,11 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         work = _scratch("work", int(_lib.load().acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, m)), torch.uint8, corpus.device)
         B = None if planar or bits_path_supported(batch) or fused_align_supported(batch) \
             else _scratch("B", max(batch.total_crp, 1), torch.uint8, corpus.device, zero=True)
-        bits_buf = _scratch("bits", max(batch.K * (batch.max_nx - m + 1) * 16, 1), torch.int64, corpus.device) \
+        bits_buf = _scratch("bits", max(batch.K * (batch.max_nx - m + 1) * bits_words(batch), 1), torch.int64, corpus.device) \
             if (planar or bits_path_supported(batch)) else None
         denom = (batch.M + batch.N).astype(np.float64)
         if "swc" in want and not (planar or bits_path_supported(batch)):
-            # matrices beyond 1024 x 1024: byte mask + dp_wave_kernel / dp_block_kernel
+            # no bit-mask path for this batch: byte mask + dp_wave_kernel / dp_block_kernel
             B = _scratch("B", max(batch.total_crp, 1), torch.uint8, corpus.device, zero=True)
             crp(corpus, batch, xp, sqrt_out=False, out=T)
             binarize(T, batch, kappa, mutual=True, out=B, work=work)

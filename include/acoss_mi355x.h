@@ -226,13 +226,16 @@ int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *de
                             int max_nx, int max_ny, int mutual, const void *work, size_t work_bytes,
                             int boundary, const acoss_align_params *params, float *scores, void *stream);
 
-/* Bit-mask path (matrices up to 1024 x 1024).  acoss_mask_bits_batch = acoss_binarize_batch with the mask
- * bit-packed: bits[(p*max_m + i)*16 + w] holds columns 64w .. 64w+63 of row i of pair p (max_m = max_nx-win+1;
- * bit c = column 64w + c; bits past the row end are zero).  The selection kernels emit each row's and each
+/* Bit-mask path.  acoss_mask_bits_batch (matrices up to 1024 x 1024) = acoss_binarize_batch with the mask
+ * bit-packed: bits[(p*max_m + i)*W + w] holds columns 64w .. 64w+63 of row i of pair p (max_m = max_nx-win+1;
+ * bit c = column 64w + c; bits past the row end are zero; W = acoss_mask_bits_words() = 16 when both matrix
+ * dimensions of the batch are <= 1024, else 32: acoss_mask_bits_planar_batch and the acoss_align_bits_* calls go
+ * up to 2048 x 2048).  The selection kernels emit each row's and each
  * column's selected positions as bit vectors by ballot; a tile kernel transposes the column vectors and ANDs.
  * `work` needs acoss_mask_bits_work_bytes() bytes (thresholds + the two bit planes).
  * acoss_align_bits_batch runs qmax (kind 0) / dmax (kind 1) / swalignimpconstrained (kind 2) from those bits, one wave per pair
  * (gamma_onset == gamma_extension required; `boundary` as for acoss_dmax_batch). */
+int acoss_mask_bits_words(int max_nx, int max_ny, int win);
 size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win);
 int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                           double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);

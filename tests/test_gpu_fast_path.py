@@ -306,3 +306,52 @@ def test_full_size_properties(eng, orc):
     assert np.array_equal(fast["qmax"], staged["qmax"]) and np.array_equal(fast["dmax"], staged["dmax"])
     oq, od, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs[:6], nthreads=6)
     assert np.array_equal(fast["qmax"][:6], oq) and np.array_equal(fast["dmax"][:6], od)
+
+
+def test_wide_forms_up_to_2048(eng, orc):
+    """Matrices between 1024 x 1024 and 2048 x 2048 (songs of 1033 .. 2056 frames): the 32-values-per-lane forms of
+    the selection kernels, the 32-word bit planes and the alignment kernels against the byte-mask path (bit-serial
+    selection on the float64 matrix, `dp_wave_kernel`), incl. the crafted tie cases; then the chain against the
+    oracle on two pairs."""
+    import torch
+    from acoss_amd import synth
+    lens = iter([2056, 1033, 300, 1500, 9, 1990])
+    ch = synth.make_corpus(3, 2, seed=611, lengths=lambda r: next(lens))
+    rng = np.random.default_rng(6)
+    pat7 = rng.random((7, 12)) + 0.1
+    A = np.tile(pat7, (200, 1))[:1300]                       # periodic: exact ties in every row and column
+    C = A + 1e-11 * rng.random(A.shape)                      # shared high words
+    feats = np.concatenate([ch.feats, A, C])
+    off = np.concatenate([ch.frame_off, ch.frame_off[-1] + np.cumsum([len(A), len(C)])]).astype(np.int64)
+    gc = np.concatenate([ch.gchroma, np.stack([x.sum(0) / x.sum(0).max() for x in (A, C)])])
+    corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+    pairs = np.array([(0, 1), (1, 0), (2, 3), (3, 5), (5, 0), (4, 0), (0, 4), (0, 0), (6, 7), (7, 6), (6, 6), (1, 6), (3, 3)], dtype=np.int32)
+    for align in (32, 1):
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+        assert eng.bits_words(batch) == 32 and eng.planar_supported(corpus, batch)
+        eng.oti(corpus, batch)
+        xp = eng.pack_x(corpus, batch)
+        T = eng.crp(corpus, batch, xp)
+        planes = eng.crp_planar(corpus, batch, xp)
+        mats, _ = batch.mats()
+        for mutual in (True, False):
+            for kappa in ((0.095, 0.5, 3, 0) if align == 32 else (0.095,)):
+                B = eng.binarize(T, batch, kappa, mutual=mutual)
+                bits, _ = eng.mask_bits_planar(planes, corpus, batch, kappa, mutual=mutual)
+                for p in range(batch.K):
+                    d = batch.descs[p]
+                    M, N = int(batch.M[p]), int(batch.N[p])
+                    want = B[int(d["crp_off"]):int(d["crp_off"]) + M * int(d["crp_pitch"])].cpu().numpy().reshape(M, -1)[:, :N]
+                    assert np.array_equal(eng.unpack_mask_bits(bits, batch, p), want), (align, mutual, kappa, p)
+                if kappa != 0.095:
+                    continue
+                for kind, kw in (("qmax", {}), ("dmax", {}), ("dmax", {"boundary": 1}), ("swc", {})):
+                    a = eng.align_bits(kind, bits, batch, **kw).cpu().numpy()
+                    b = eng.align(kind, B, mats, **kw).cpu().numpy()
+                    assert np.array_equal(a, b), (align, mutual, kind, kw)
+                q, dm = eng.align_bits_qd(bits, batch, boundary=1)
+                assert torch.equal(q, eng.align_bits("qmax", bits, batch)) and torch.equal(dm, eng.align_bits("dmax", bits, batch, boundary=1))
+    got = eng.serra09_scores(corpus, pairs[[0, 3]])
+    for t, (i, j) in enumerate(pairs[[0, 3]]):
+        q, dm = orc.serra09_pair(feats[off[i]:off[i + 1]], gc[i], feats[off[j]:off[j + 1]], gc[j])
+        assert got["qmax"][t] == q and got["dmax"][t] == dm, (i, j)

@@ -148,3 +148,25 @@ def test_randomised_ragged_pairs_against_oracle(orc):
     got = engine.serra09_scores(corpus, pairs)
     q, d, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=min(os.cpu_count() or 1, 16))
     assert np.array_equal(got["qmax"], q) and np.array_equal(got["dmax"], d)
+
+
+def test_songs_longer_than_2056_frames(orc):
+    """No length limit in the reference (it scores whole tracks): matrices beyond 2048 x 2048 go through the any-size
+    radix selection, the byte mask and the LDS-resident alignment kernel.  Scores equal the oracle's; swalignimpconstrained
+    within 1e-5.  (Exact ties on this path: tests/test_gpu_stages.py::test_binarize_ties_and_negative_values.)"""
+    from acoss_amd import engine, synth
+    engine.require_gpu()
+    lens_it = iter([2300, 400, 2070, 3000, 2057])
+    ch = synth.make_corpus(5, 1, seed=99, lengths=lambda r: next(lens_it))
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = np.array([(0, 1), (1, 0), (2, 3), (3, 0), (4, 4), (1, 1), (4, 2)], dtype=np.int32)
+    got = engine.serra09_scores(corpus, pairs, want=("qmax", "dmax", "swc"))
+    for t, (i, j) in enumerate(pairs):
+        X, Y = ch.song(i), ch.song(j)
+        q, d = orc.serra09_pair(X, ch.gchroma[i], Y, ch.gchroma[j])
+        assert got["qmax"][t] == q and got["dmax"][t] == d, (t, i, j, got["qmax"][t], q, got["dmax"][t], d)
+        if t in (0, 6):
+            B = orc.csm_to_binary_mutual(orc.sliding_csm(orc.get_csm(X, Y, orc.get_oti(ch.gchroma[i], ch.gchroma[j])), 9), 0.095)
+            M, N = B.shape
+            sw = orc.swconstrained(np.ascontiguousarray(B.flatten()), np.zeros((M + 1) * (N + 1), dtype=np.float32), M, N) / (M + N)
+            assert abs(got["swc"][t] - sw) <= 1e-5

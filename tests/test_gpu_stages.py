@@ -141,7 +141,9 @@ def test_binarize_ties_and_negative_values(orc):
     the GPU resolves ties lowest-index first, exactly like the oracle."""
     from acoss_amd import CRPUtils
     rng = np.random.default_rng(3)
-    for shape, kappa in [((37, 53), 0.2), ((64, 64), 0.1), ((100, 129), 9)]:
+    # (beyond 2048 rows / columns: the any-size radix selection, select_generic_kernel)
+    for shape, kappa in [((37, 53), 0.2), ((64, 64), 0.1), ((100, 129), 9), ((30, 2500), 0.1), ((2500, 30), 0.3),
+                         ((2100, 2060), 0.095), ((2049, 2049), 700)]:
         D = np.round(rng.standard_normal(shape) * 2) / 2      # many exact ties, both signs, +-0
         D[3, :] = 0.0
         D[:, 5] = -0.0

@@ -1,4 +1,4 @@
-"""Throughput of the chain on songs longer than 1032 frames (matrices beyond 1024 x 1024: byte-mask path) (dev tool)."""
+"""Throughput of the chain on songs longer than 1032 frames (32-values-per-lane kernels up to 2056 frames, any-size kernels beyond) (dev tool)."""
 import os, sys, time
 import numpy as np
 import torch
