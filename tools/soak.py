@@ -7,8 +7,12 @@ from oracle import oracle
 engine.require_gpu()
 n_pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+long_songs = len(sys.argv) > 3 and sys.argv[3] == "long"       # lengths 60 .. 2600: all three size classes of the chain
 rng = np.random.default_rng(seed)
-ch = synth.make_corpus(40, 8, seed=seed, singletons=30, lengths=lambda r: int(np.clip(r.normal(520, 160), 60, 1032)))
+if long_songs:
+    ch = synth.make_corpus(12, 4, seed=seed, singletons=8, lengths=lambda r: int(np.clip(r.normal(1300, 600), 60, 2600)))
+else:
+    ch = synth.make_corpus(40, 8, seed=seed, singletons=30, lengths=lambda r: int(np.clip(r.normal(520, 160), 60, 1032)))
 corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
 allp = synth.all_pairs(ch.n_songs)
 pairs = allp[rng.permutation(len(allp))[:n_pairs]]
