@@ -359,6 +359,12 @@ def main():
             out[key] = {"kernel": kname2, "bound": "hbm", "achieved": round(cb / cms / 1e6, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(cb / cms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": cb,
                         "avg_launch_ms": round(cms, 4)}
+        # context for those fractions: what a plain streaming store of the same byte count reaches on this GPU
+        # (torch fill_ into the same buffer; 33.5 GB in one launch runs at ~4.7 TB/s, 16 GB at ~6.2 TB/s)
+        fms = time_kernel(lambda: C.fill_(1.0))
+        fb = C.numel() * C.element_size()
+        out["hbm_write_ceiling"] = {"kernel": "torch fill_ of the CSM buffer, %d bytes (plain streaming stores)" % fb,
+                                    "achieved": round(fb / fms / 1e6, 1), "unit": "GB/s", "avg_launch_ms": round(fms, 4)}
         del C
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
