@@ -255,7 +255,9 @@ __global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kerne
 // in columns 2v and 2v + 1, the second one inside the window predicted by the first.  Once a wave holds its
 // two columns in registers their LDS slots become its histogram.
 constexpr int PL_COLS = 16;
-constexpr int PL_LDC = 1024 + 4;        // words per staged column
+constexpr int PL_LDC = 512 + 36;        // words per staged half column (two of them hold one wave's histogram; column pairs 8 banks apart)
+
+static_assert(2 * (512 + 36) >= HIST_WORDS, "a wave's two half-column slots hold its histogram");
 
 template <int MODE = 0>
 __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32_t *__restrict__ Thi,
@@ -269,6 +271,7 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
     if (j0 >= N) return;
+    unsigned ha[16], hb[16];
     {
         // 64 rows x 8 column pairs per sweep (8-byte loads, 64-byte row segments), 16 sweeps (M <= 1024).
         // (16-byte loads with 4 lanes per row segment take 2.3x as long: measured.)
@@ -293,30 +296,39 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
                 tmp[s].y = Thi[ri + min(j0 + 2 * cc + 1, N - 1)];
             }
         }
+        // staged in two halves of 512 rows (35 KB of LDS: three blocks per CU instead of two).  Slot s*64 + rr of a
+        // column holds row min(s*64 + rr, M-1), so the readers need no clamp.
+        const int wave_ = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+        const int lane_ = threadIdx.x & 63;
 #pragma unroll
-        for (int s = 0; s < 16; s++) {
-            unsigned *dst = pcolbuf + (2 * c2) * PL_LDC + s * 64 + rr;
-            dst[0 * PL_LDC] = tmp[s].x;
-            dst[1 * PL_LDC] = tmp[s].y;
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();              // every wave has read the first half
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                unsigned *dst = pcolbuf + (2 * c2) * PL_LDC + s * 64 + rr;
+                dst[0 * PL_LDC] = tmp[half * 8 + s].x;
+                dst[1 * PL_LDC] = tmp[half * 8 + s].y;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 8; e++) {
+                ha[half * 8 + e] = pcolbuf[(2 * wave_) * PL_LDC + e * 64 + lane_];
+                hb[half * 8 + e] = pcolbuf[(2 * wave_ + 1) * PL_LDC + e * 64 + lane_];
+            }
         }
     }
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int ja = j0 + 2 * wave;
     if (ja >= N) return;
     if constexpr (MODE == 1) {
-        if (pcolbuf[(2 * wave) * PL_LDC + lane] == 0x12345u) w.col_cut[0] = 0;
+        unsigned acc = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) acc += ha[e] + hb[e];
+        if (acc == 0x12345u) w.col_cut[0] = 0;
         return;
     }
-    unsigned ha[16], hb[16];
-#pragma unroll
-    for (int e = 0; e < 16; e++) {
-        const int row = min(e * 64 + lane, M - 1);
-        ha[e] = pcolbuf[(2 * wave) * PL_LDC + row];
-        hb[e] = pcolbuf[(2 * wave + 1) * PL_LDC + row];
-    }
-    unsigned *hist = pcolbuf + (2 * wave) * PL_LDC;      // 2 * PL_LDC words >= HIST_WORDS, 16-byte aligned
+    unsigned *hist = pcolbuf + (2 * wave) * PL_LDC;      // the wave's two slots: 2 * PL_LDC words >= HIST_WORDS, 16-byte aligned
     hist_clear(hist, lane);
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<16>(M, lane);
