@@ -375,7 +375,7 @@ typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // gfx9 raw buffer: 32-bit data format, no swizzle
 
-// MODE (development probes, product = 0): 1 = no result stores, 2 = no window sums (store a C value),
+// MODE (development probes, product = 0; 4 = 1 + 2, 5 = 1 + 3): 1 = no result stores, 2 = no window sums (store a C value),
 // 3 = no MFMA phase (stale LDS contents summed)
 // CSM_LAYOUT: write at the pair's csm_off / csm_pitch instead of crp_off / crp_pitch (WIN = 1 with
 // SQRT_OUT is then exactly get_csm, CRPUtils.py:67-84).
@@ -495,7 +495,15 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         if (loader_ && t + 2 < n_steps)
             xn2 = reinterpret_cast<const double2 *>(xsrc)[min((t + 2) * STRIP_ROWS * (XP_STRIDE / 2) + tid_, last_chunk)];
         // ---- C rows [32t, 32t+32) of this wave's 16 columns -> cbuf rows [HALO, HALO+32)
-        if (MODE != 3) {
+        if (MODE != 3 && MODE != 5) {
+            // the norms of the lane's 8 x rows are read together with the A fragments, and |x|^2 + |y|^2 is formed while
+            // the matrix-core chain runs: read -> wait -> write once per value would put 8 LDS round trips in a row here
+            double nsum[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) nsum[rb][r] = xs[(16 * rb + lk_ + 4 * r) * XS_LD + D];
+            }
             v4f64 acc[2];
             acc[0] = (v4f64){0.0, 0.0, 0.0, 0.0};
             acc[1] = (v4f64){0.0, 0.0, 0.0, 0.0};
@@ -510,10 +518,18 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
 #pragma unroll
             for (int rb = 0; rb < 2; rb++) {
 #pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const double c = fma(-2.0, acc[rb][r], xs[(16 * rb + lk_ + 4 * r) * XS_LD + D] + yy);
-                    wr_[(16 * rb + 4 * r) * CRP_LD] = fmax(c, 0.0);
-                }
+                for (int r = 0; r < 4; r++) nsum[rb][r] = nsum[rb][r] + yy;
+            }
+            double cv[2][4];
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) cv[rb][r] = fmax(fma(-2.0, acc[rb][r], nsum[rb][r]), 0.0);
+            }
+#pragma unroll
+            for (int rb = 0; rb < 2; rb++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) wr_[(16 * rb + 4 * r) * CRP_LD] = cv[rb][r];
             }
         }
         lds_barrier();
@@ -537,13 +553,12 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
 #pragma unroll
             for (int q = 0; q < ROWS_PER_WAVE; q++) {
                 const int gi = g0 + q;
-                double sa = 0.0, sb = 0.0;
-                if (MODE == 2) {
-                    sa = va[q];
-                    sb = vb[q];
-                } else {
+                // (the C values are never -0.0 -- max(fma(-2, dot, |x|^2 + |y|^2), 0) with non-negative norms -- so starting
+                // the chain at the first addend gives the bits of 0.0 + c0 + c1 + ..., the form every other kernel uses)
+                double sa = va[q], sb = vb[q];
+                if (MODE != 2 && MODE != 4) {
 #pragma unroll
-                    for (int k = 0; k < WIN; k++) {
+                    for (int k = 1; k < WIN; k++) {
                         sa += va[q + k];
                         sb += vb[q + k];
                     }
@@ -578,7 +593,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     const int soff = 8 * (orow0 + (t * STRIP_ROWS + q) * o_pitch);      // wave-uniform byte offset of (row, strip column 0)
                     const u32x2_t wa = {(unsigned)__double2loint(sa), (unsigned)__double2hiint(sa)};
                     const u32x2_t wb = {(unsigned)__double2loint(sb), (unsigned)__double2hiint(sb)};
-                    if (MODE == 1) {
+                    if (MODE == 1 || MODE == 4 || MODE == 5) {
                         if (sa == -1.25) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * (col & 63), soff, 0);
                     } else if (CHECKED) {
                         const bool row_ok = gi >= 0 && gi < M;
@@ -791,6 +806,8 @@ int acoss_dev_crp_probe(int mode, const double *xp, const double *feats, const d
     if (mode == 1) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 1>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else if (mode == 2) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 2>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else if (mode == 3) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 3>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else if (mode == 4) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 4>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+    else if (mode == 5) hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 5>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 0>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     return launch_check("crp_strip probe");
 }

@@ -16,7 +16,7 @@ lib = _lib.load()
 fn = lib.acoss_dev_crp_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2
-names = {0: "normal", 1: "no stores", 2: "no window sums", 3: "no MFMA phase"}
+names = {0: "normal", 1: "no stores", 2: "no window sums", 3: "no MFMA phase", 4: "no stores, no sums", 5: "no stores, no MFMA"}
 res = {m: [] for m in names}
 for rnd in range(5):
     for m in names:
