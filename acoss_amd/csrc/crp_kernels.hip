@@ -395,7 +395,7 @@ __device__ inline uint64_t slot_valid_masks(IdxFn idx_of, int n, int lane)
 
 template <typename IdxFn>
 __device__ inline void emit_select_bits(const double (&x)[16], IdxFn idx_of, uint64_t valid, const SelectResult &r,
-                                        uint64_t *out, int lane)
+                                        uint64_t *out, int lane, int64_t stride = 1)
 {
     const double tv = r.thr_key == ~0ull ? INFINITY : (r.thr_key == 0ull ? -INFINITY : f64_from_key(r.thr_key));
     unsigned lo = 0, hi = 0;
@@ -412,7 +412,7 @@ __device__ inline void emit_select_bits(const double (&x)[16], IdxFn idx_of, uin
             put_lane_u64(lo, hi, m, e);
         }
     }
-    if (lane < 16) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
+    if (lane < 16) out[lane * stride] = (((uint64_t)hi << 32) | lo) & valid;
 }
 
 template <int EPL, bool HIST = false>
@@ -561,7 +561,7 @@ __global__ __launch_bounds__(SEL_COLS_THREADS, 4) void select_cols_kernel(const 
                 double x[16];
 #pragma unroll
                 for (int e = 0; e < 16; e++) x[e] = 0.0;
-                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_word(p, j, 0), lane, w.max_n);
             }
         }
     } else {
@@ -580,7 +580,7 @@ __global__ __launch_bounds__(SEL_COLS_THREADS, 4) void select_cols_kernel(const 
                 res = wave_select16_hist(x, ColIdx{lane}, M, k, hist, lane, hw);
             }
             if (w.col_bits && res.cut != SELECT_UNRESOLVED)
-                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+                emit_select_bits(x, ColIdx{lane}, slot_valid_masks(ColIdx{lane}, M, lane), res, w.col_word(p, j, 0), lane, w.max_n);
         } else {
             uint64_t key[EPL];
             int idx[EPL];
@@ -635,7 +635,8 @@ __global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict
         }
         uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
         if (bits) {
-            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * 16;
+            bits = DIR == 0 ? w.row_bits + ((int64_t)p * w.max_m + which) * 16 : w.col_word(p, which, 0);
+            const int64_t bstride = DIR == 0 ? 1 : w.max_n;
             uint64_t mine = 0;
 #pragma unroll
             for (int e = 0; e < 16; e++) {
@@ -643,7 +644,7 @@ __global__ __launch_bounds__(64) void select_fix_kernel(const double *__restrict
                 const uint64_t m = __ballot(on);
                 if (lane == e) mine = m;
             }
-            if (lane < 16) bits[lane] = mine;
+            if (lane < 16) bits[lane * bstride] = mine;
         }
     }
 }
@@ -660,42 +661,57 @@ __device__ inline uint64_t spread_bits32(unsigned a)
     return x;
 }
 
+// 64 x 64 bit transpose across a wave: lane r holds row r (bit c = column c) -> lane c holds column c (bit r = row r).
+// Six butterfly steps (block sizes 32 .. 1): lanes r and r ^ j exchange the off-diagonal j x j blocks of every 2j x 2j
+// block; ~70 instructions instead of 64 ballots.
+__device__ inline uint64_t wave_transpose64(uint64_t x, int lane)
+{
+#pragma unroll
+    for (int j = 32; j >= 1; j >>= 1) {
+        // columns c with (c & j) == 0
+        const uint64_t m = j == 32 ? 0x00000000ffffffffull : j == 16 ? 0x0000ffff0000ffffull : j == 8 ? 0x00ff00ff00ff00ffull
+                         : j == 4 ? 0x0f0f0f0f0f0f0f0full : j == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+        const unsigned ylo = (unsigned)__shfl_xor((int)(unsigned)x, j);
+        const unsigned yhi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), j);
+        const uint64_t y = ((uint64_t)yhi << 32) | ylo;
+        x = (lane & j) ? ((x & ~m) | ((y & ~m) >> j)) : ((x & m) | ((y & m) << j));
+    }
+    return x;
+}
+
 // Bit-packed mutual mask: out[p][i][cw] (uint64, bit c = column cw*64 + c) = row_bits[i][cw] & the transpose
-// of col_bits.  One wave per 64 x 64 tile: lane l loads the column word of column cw*64 + l covering rows
-// ri*64 .. ri*64+63, 64 ballots transpose it, lane r ends with the row word of row ri*64 + r.
+// of col_bits.  One block per 64 rows of a pair: the rows' words come in and go out through LDS with fully
+// coalesced accesses (64 rows x W words are contiguous in both arrays); wave v takes the 64 x 64 tiles cw = v, v+4, ...:
+// lane l loads the column word of column cw*64 + l covering rows ri*64 .. ri*64+63, a butterfly transpose
+// (wave_transpose64) turns it, lane r ends with the row word of row ri*64 + r.
+constexpr int COMBINE_MAXW = 32;
+
 __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc *__restrict__ descs, int K, int win,
-                                                           int mutual, ThreshWork w, int tiles_m, int tiles_n,
+                                                           int mutual, ThreshWork w, int tiles_m,
                                                            uint64_t *__restrict__ out)
 {
-    const int tiles = tiles_m * tiles_n;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int64_t tw = (int64_t)blockIdx.x * 4 + wave;
-    if (tw >= (int64_t)K * tiles) return;
-    const int p = (int)(tw / tiles), t = (int)(tw % tiles);
+    __shared__ uint64_t rowbuf[64 * (COMBINE_MAXW + 1)];
+    const int p = blockIdx.x / tiles_m, ri = blockIdx.x % tiles_m;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    const int ri = t / tiles_n, cw = t % tiles_n;
     if (ri * 64 >= M) return;
+    const int W = w.wpr, ld = W + 1;
+    const int rows = min(64, M - ri * 64);
+    const int64_t base = ((int64_t)p * w.max_m + ri * 64) * W;          // the block's rows are contiguous: rows * W words
+    for (int idx = threadIdx.x; idx < rows * W; idx += 256) rowbuf[(idx / W) * ld + idx % W] = w.row_bits[base + idx];
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
-    const int i = ri * 64 + lane;
-    uint64_t rw = 0;
-    if (i < M && cw * 64 < N) {
-        rw = w.row_bits[((int64_t)p * w.max_m + i) * w.wpr + cw];
-    }
     if (mutual) {
-        const int j = cw * 64 + lane;
-        const uint64_t cwd = j < N ? w.col_bits[((int64_t)p * w.max_n + j) * w.wpr + ri] : 0ull;
-        const unsigned clo = (unsigned)cwd, chi = (unsigned)(cwd >> 32);
-        uint64_t tr = 0;
-#pragma unroll
-        for (int r = 0; r < 64; r++) {
-            const unsigned bit = r < 32 ? ((clo >> r) & 1u) : ((chi >> (r - 32)) & 1u);
-            const uint64_t m = __ballot(bit != 0u);
-            if (lane == r) tr = m;
+        for (int cw = wave; cw * 64 < N; cw += 4) {
+            const int j = cw * 64 + lane;
+            const uint64_t cwd = j < N ? *w.col_word(p, j, ri) : 0ull;
+            const uint64_t tr = wave_transpose64(cwd, lane);
+            if (lane < rows) rowbuf[lane * ld + cw] &= tr;
         }
-        rw &= tr;
     }
-    if (i < M) out[((int64_t)p * w.max_m + i) * w.wpr + cw] = rw;
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < rows * W; idx += 256) out[base + idx] = rowbuf[(idx / W) * ld + idx % W];
 }
 
 
@@ -942,9 +958,9 @@ static void kappa_mode(double kappa, double &kv, int &mode)
 // shared with planar_kernels.hip
 int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st)
 {
-    const int tm = ceil_div(w.max_m, 64), tn = w.wpr;     // every word of every row is written
-    const int64_t waves = (int64_t)K * tm * tn;
-    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)ceil_div64(waves, 4)), dim3(256), 0, st, descs, K, win, mutual, w, tm, tn, bits);
+    const int tm = ceil_div(w.max_m, 64);       // every word of every row is written
+    if (w.wpr > COMBINE_MAXW || (int64_t)K * tm > 0x7fffffffLL) { set_error("combine_bits: batch too large"); return ACOSS_ENOTSUP; }
+    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)((int64_t)K * tm)), dim3(256), 0, st, descs, K, win, mutual, w, tm, bits);
     return launch_check("combine_bits_kernel");
 }
 

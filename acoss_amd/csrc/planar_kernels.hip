@@ -39,12 +39,13 @@ __device__ inline uint64_t planar_slot_valid(int n, int lane)
 
 // word e of out = lanes whose element e is selected (high word <= the threshold's), positions e*64 + lane
 template <int E>
-__device__ inline void planar_emit_bits(const unsigned (&h)[E], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane)
+__device__ inline void planar_emit_bits(const unsigned (&h)[E], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane,
+                                        int64_t stride = 1)
 {
     unsigned lo = 0, hi = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) planar_put_lane_u64(lo, hi, __ballot(h[e] <= thr_hi), e);
-    if (lane < E) out[lane] = (((uint64_t)hi << 32) | lo) & valid;
+    if (lane < E) out[lane * stride] = (((uint64_t)hi << 32) | lo) & valid;
 }
 
 // k-th smallest of the n high words a wave holds (h[e] = position e*64 + lane; positions >= n repeat a real
@@ -343,7 +344,7 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
         }
         if (w.col_bits && res.cut != SELECT_UNRESOLVED)
             planar_emit_bits<16>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
-                                 w.col_bits + ((int64_t)p * w.max_n + j) * 16, lane);
+                                 w.col_word(p, j, 0), lane, w.max_n);
     };
     column(ha, ja);
     if (ja + 1 < N) column(hb, ja + 1);
@@ -416,7 +417,7 @@ __global__ __launch_bounds__(64 * COLS) void select_cols_planar_wide_kernel(cons
     }
     if (w.col_bits && res.cut != SELECT_UNRESOLVED)
         planar_emit_bits<32>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
-                             w.col_bits + ((int64_t)p * w.max_n + j) * 32, lane);
+                             w.col_word(p, j, 0), lane, w.max_n);
 }
 
 // ---- fix-up: rows / columns whose winner shares its high word -----------------------------------------------
@@ -484,7 +485,8 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
         }
         uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
         if (bits) {
-            bits += ((int64_t)p * (DIR == 0 ? w.max_m : w.max_n) + which) * E;
+            bits = DIR == 0 ? w.row_bits + ((int64_t)p * w.max_m + which) * E : w.col_word(p, which, 0);
+            const int64_t bstride = DIR == 0 ? 1 : w.max_n;
             uint64_t mine = 0;
 #pragma unroll
             for (int e = 0; e < E; e++) {
@@ -492,7 +494,7 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
                 const uint64_t m = __ballot(on);
                 if (lane == e) mine = m;
             }
-            if (lane < E) bits[lane] = mine;
+            if (lane < E) bits[lane * bstride] = mine;
         }
     }
 }

@@ -17,8 +17,10 @@ struct ThreshWork {
     // optional (bit-mask path): the selected positions of every row / column, wpr x uint64 each (bit l of word e =
     // position 64 e + l); wpr = mask_bits_words(max_m, max_n)
     uint64_t *row_bits;  // [K][max_m][wpr]
-    uint64_t *col_bits;  // [K][max_n][wpr]
+    uint64_t *col_bits;  // [K][wpr][max_n]: word-major, so that word e of 64 neighbouring columns is one 512-byte run
+                         // (what the transposing combine kernel reads); column j's word e = col_word(p, j, e)
     int wpr;
+    __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };
 
 // uint64 words per row of the bit planes and of the bit-packed mask: 16 up to 1024 x 1024, 32 up to 2048 x 2048
