@@ -303,7 +303,7 @@ def main():
     # HBM bytes per launch of that kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE exact,
     # FETCH_SIZE x2 on gfx950) -- only quoted when the profile was taken on this very workload
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_planar_pmc.json")
+    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc.json")
     pmc_key = {"fast": "crp_strip_kernel<12, 9, false, 0, false, true>"}.get(args.path)
     if pmc_key and runner.planar and args.frames == 1000 and os.path.exists(pmc_file):
         with open(pmc_file) as fh:
@@ -311,7 +311,7 @@ def main():
         c = doc.get(pmc_key)
         if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
             traffic = round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9)
-            traffic_src = "profiles/r01_planar_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
+            traffic_src = "profiles/r01_final_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
     if runner.planar:
         kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
     out = {
