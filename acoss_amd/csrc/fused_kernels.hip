@@ -476,7 +476,10 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         const int lane_ = tid_ & 63;
         const int lr_ = lane_ & 15, lk_ = lane_ >> 4;
         const bool loader_ = tid_ < STRIP_ROWS * (XP_STRIDE / 2);
-        double *xs_dst_ = &xs[(tid_ >> 3) * XS_LD + (tid_ & 7) * 2];
+        // (24-bit multiplies and unsigned shifts: the laundered thread id is opaque to the compiler, which would emit
+        // quarter-rate 32-bit multiplies and signed-division sequences for these)
+        const unsigned ut_ = (unsigned)tid_;
+        double *xs_dst_ = &xs[__umul24(ut_ >> 3, (unsigned)XS_LD) + (ut_ & 7u) * 2u];
         const int ca_ = lane_, cb_ = lane_ + 64;
         const bool oka_ = ca_ < TN && j0 + ca_ < N, okb_ = cb_ < TN && j0 + cb_ < N;
         const int cbr_ = okb_ ? cb_ : ca_;
@@ -486,9 +489,10 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
         const int dcol_ = 2 * lane_ - ROWS_PER_WAVE;
         const double *rdd_ = cbuf + (wave * ROWS_PER_WAVE) * CRP_LD + dcol_;
         const bool copier_ = tid_ < HALO * (CRP_CT / 2);
-        const int hrow_ = (2 * tid_) / CRP_CT, hcol_ = (2 * tid_) % CRP_CT;
-        double *halo_src_ = cbuf + ((copier_ ? STRIP_ROWS + hrow_ : 0)) * CRP_LD + hcol_;
-        double *halo_dst_ = cbuf + (copier_ ? hrow_ : 0) * CRP_LD + hcol_;
+        static_assert(CRP_CT == 128, "halo copy: two elements per thread, 64 threads per row");
+        const unsigned hrow_ = ut_ >> 6, hcol_ = (2u * ut_) & 127u;
+        double *halo_src_ = cbuf + __umul24(copier_ ? STRIP_ROWS + hrow_ : 0u, (unsigned)CRP_LD) + hcol_;
+        double *halo_dst_ = cbuf + __umul24(copier_ ? hrow_ : 0u, (unsigned)CRP_LD) + hcol_;
         (void)rda_; (void)rdb_; (void)rdd_; (void)oka_; (void)okb_; (void)cb_;
         constexpr bool CHECKED = decltype(checked_tag)::value;
         const bool more = t + 1 < n_steps;
