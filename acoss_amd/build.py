@@ -12,7 +12,7 @@ import sys
 PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIB = os.path.join(PKG, "libacoss_mi355x.so")
-SOURCES = ["capi.hip", "crp_kernels.hip", "fused_kernels.hip", "dp_kernels.hip", "planar_kernels.hip", "eval_kernels.hip", "ftm2d_kernels.hip", "snf_kernels.hip", "probe_kernels.hip"]
+SOURCES = ["capi.hip", "crp_kernels.hip", "fused_kernels.hip", "strip32_kernels.hip", "dp_kernels.hip", "planar_kernels.hip", "eval_kernels.hip", "ftm2d_kernels.hip", "snf_kernels.hip", "probe_kernels.hip"]
 HEADERS = ["common.h", "wave_ops.h", "kernel_utils.h", "thresh_work.h", "gemm_f64.h", os.path.join("..", "..", "include", "acoss_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",

@@ -8,6 +8,9 @@
 //   mode 3: bands   -- workgroup = 16 full rows of a matrix (one contiguous 16 * cols * 8 byte region)
 //   mode 4: band of 64 rows, column-chunk-major -- wave w takes the 128-column chunks w, w+4, ... and writes the 64 row
 //           pieces of a chunk before moving on (a y-stationary kernel that owns whole rows)
+//   mode 6: the planar form: a uint32 matrix (4 bytes per cell, rows x cols cells in the first half of each matrix's
+//           space), 120-column strips walked down, one 8-byte store per lane: 480-byte row pieces
+//   mode 7: the same with 240-column strips, one 16-byte store per lane: 960-byte row pieces
 //   mode 5: band of 32 rows walked in 120-column steps -- each step writes 32 pieces of 960 bytes (the strip kernel
 //           turned by 90 degrees)
 #include "common.h"
@@ -57,6 +60,30 @@ __global__ __launch_bounds__(256) void store_probe_kernel(double *__restrict__ o
             for (int r = r0; r < r1; r++)
                 if (c + 1 < cols) *reinterpret_cast<double2 *>(M + (int64_t)r * cols + c) = v;
         }
+    } else if (mode == 9) {
+        // float64, 112-column strips: 896-byte row pieces = 7 whole 128-byte lines when the pitch is line-aligned
+        const int c = t * 112 + (tid & 63) * 2;
+        const bool on = (tid & 63) < 56 && c + 1 < cols;
+        for (int r = tid >> 6; r < rows; r += 4)
+            if (on) *reinterpret_cast<double2 *>(M + (int64_t)r * cols + c) = v;
+    } else if (mode == 8) {
+        // 112-column strips of a uint32 matrix: 448-byte row pieces, every piece 64-byte aligned when the pitch is
+        uint32_t *U = reinterpret_cast<uint32_t *>(out) + (int64_t)p * rows * cols;
+        const int c = t * 112 + (tid & 63) * 2;
+        const bool on = (tid & 63) < 56 && c + 1 < cols;
+        for (int r = tid >> 6; r < rows; r += 4)
+            if (on) *reinterpret_cast<uint2 *>(U + (int64_t)r * cols + c) = make_uint2(tid, r);
+    } else if (mode == 6 || mode == 7) {
+        uint32_t *U = reinterpret_cast<uint32_t *>(out) + (int64_t)p * rows * cols;        // 4 bytes per cell
+        const int w = mode == 6 ? 120 : 240, per = mode == 6 ? 2 : 4;
+        const int c = t * w + (tid & 63) * per;
+        const bool on = (tid & 63) < 60 && c + per - 1 < cols;
+        for (int r = tid >> 6; r < rows; r += 4) {
+            if (on) {
+                if (mode == 6) *reinterpret_cast<uint2 *>(U + (int64_t)r * cols + c) = make_uint2(tid, r);
+                else *reinterpret_cast<uint4 *>(U + (int64_t)r * cols + c) = make_uint4(tid, r, 3, 4);
+            }
+        }
     } else {
         const int r0 = t * 32, r1 = min(r0 + 32, rows);
         for (int c0 = 0; c0 < cols; c0 += 120) {
@@ -74,12 +101,13 @@ using namespace acoss;
 
 extern "C" int acoss_dev_store_probe(double *out, int K, int rows, int cols, int mode, void *stream)
 {
-    if (!out || K < 1 || rows < 1 || cols < 2 || (cols & 1) || mode < 0 || mode > 5) { set_error("store_probe: bad argument"); return ACOSS_EINVAL; }
+    if (!out || K < 1 || rows < 1 || cols < 2 || (cols & 3) || mode < 0 || mode > 9) { set_error("store_probe: bad argument"); return ACOSS_EINVAL; }
     int per_mat = 1;
     int64_t blocks;
     if (mode == 0) blocks = ((int64_t)K * rows * cols + 256 * 2 * 64 - 1) / (256 * 2 * 64);
     else {
-        per_mat = mode == 1 ? ((rows + 127) / 128) * ((cols + 127) / 128) : (mode == 2 ? (cols + 119) / 120 : (mode == 3 ? (rows + 15) / 16 : (mode == 4 ? (rows + 63) / 64 : (rows + 31) / 32)));
+        per_mat = mode == 1 ? ((rows + 127) / 128) * ((cols + 127) / 128) : (mode == 2 ? (cols + 119) / 120 : (mode == 3 ? (rows + 15) / 16 : (mode == 4 ? (rows + 63) / 64 : (mode == 5 ? (rows + 31) / 32 : (mode == 6 ? (cols + 119) / 120 : (mode == 7 ? (cols + 239) / 240 : (cols + 111) / 112))))));
+        if (mode == 9) per_mat = (cols + 111) / 112;
         blocks = (int64_t)K * per_mat;
     }
     if (blocks > 0x7fffffffLL) { set_error("store_probe: too large"); return ACOSS_ENOTSUP; }

@@ -208,6 +208,38 @@ def crp_planar(corpus, batch, xp, out=None):
     return out
 
 
+def float32_copy(corpus):
+    """(features, squared norms) of a float64 corpus rounded to float32, cached on the corpus: the operands of the
+    approximate strip kernel (crp_planar32)."""
+    if getattr(corpus, "_f32", None) is None:
+        corpus._f32 = (corpus.feats.to(torch.float32), corpus.norms.to(torch.float32))
+    return corpus._f32
+
+
+def pack_x32(corpus, batch, out=None):
+    """pack_x() of the float32 copy of a float64 corpus."""
+    lib = _lib.load()
+    f32, n32 = float32_copy(corpus)
+    need = int(lib.acoss_xpack_elems(batch.K, batch.max_nx))
+    if out is None or out.numel() < need:
+        out = torch.empty(max(need, 1), dtype=torch.float32, device=corpus.device)
+    check(lib.acoss_pack_x_f32(_ptr(f32), _ptr(n32), corpus.d, _ptr(batch.descs_dev), batch.K, batch.max_nx,
+                               _ptr(out), _stream()), "pack_x_f32")
+    return out
+
+
+def crp_planar32(corpus, batch, xp32, out=None):
+    """Float32 approximation of the windowed sums as order-preserving uint32 keys (float32 bits | sign bit), same
+    element indexing as crp_planar(); |approx - exact| <= 40 * 2^-24 * (window sums of the squared norms)."""
+    lib = _lib.load()
+    f32, n32 = float32_copy(corpus)
+    if out is None:
+        out = torch.empty(planar_elems(batch), dtype=torch.int32, device=corpus.device)
+    check(lib.acoss_crp_planar32_batch(_ptr(xp32), _ptr(f32), _ptr(n32), corpus.d, _ptr(batch.descs_dev), batch.K,
+                                       batch.win, batch.max_nx, batch.max_ny, _ptr(out), _stream()), "crp_planar32_batch")
+    return out
+
+
 def planar_elems(batch):
     """Words of the high-word matrix of a batch."""
     return max(batch.total_crp, 2)

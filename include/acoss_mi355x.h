@@ -181,6 +181,13 @@ int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const doubl
 int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
+/* Float32 approximation of acoss_crp_planar_batch_f64's matrix (xp, feats, norms: the float64 corpus rounded to
+ * float32, packed by acoss_pack_x_f32): the windowed sums computed in float32 and written as order-preserving uint32
+ * keys (the float32 bit pattern with the sign bit set), same element indexing.  |approx - exact| <= 40 * 2^-24 *
+ * (sum over the window of |x_{i+k}|^2 + |y_{j+k}|^2).  CRPUtils.py:67-84 + :24-45, d in {12, 13}, win == 9. */
+int acoss_crp_planar32_batch(const float *xp, const float *feats, const float *norms, int d,
+                             const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                             uint32_t *out, void *stream);
 int acoss_crp_batch_f32(const float *xp, const float *feats, const float *norms, int d,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
