@@ -172,6 +172,41 @@ __device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int 
     return res;
 }
 
+// ---- float32-approximate keys: the error band around a threshold ----------------------------------------------
+// Keys are float32 bit patterns (values >= +0) with the sign bit set.  [lo, hi] = the keys of the values within `band`
+// of the value of key th, widened by one ulp each way for the rounding of the two float operations.
+__device__ inline void band_limits(unsigned th, float band, unsigned &lo, unsigned &hi)
+{
+    const float a = __uint_as_float(th & 0x7fffffffu);
+    const float l = a - band, h = a + band;
+    lo = l > 0.0f ? (__float_as_uint(l) | 0x80000000u) - 1u : 0x80000000u;
+    hi = (__float_as_uint(h) | 0x80000000u) + 1u;
+}
+
+// number of the wave's n keys inside [lo, hi] (wave-uniform)
+template <int E>
+__device__ inline int band_count(const unsigned (&h)[E], int n, unsigned lo, unsigned hi, int lane)
+{
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) c += __popcll(__ballot((h[e] >= lo) & (h[e] <= hi) & (e * 64 + lane < n)));
+    return c;
+}
+
+// after the selection on approximate keys: the result stands only if the winner is alone in its error band
+template <int E>
+__device__ inline void band_resolve(const unsigned (&h)[E], int n, const float *band, int p, int lane, SelectResult &res)
+{
+    if (band == nullptr || res.cut == SELECT_UNRESOLVED || res.cut < 0 || res.thr_key == ~0ull) return;
+    const unsigned th = (unsigned)(res.thr_key >> 32);
+    unsigned lo, hi;
+    band_limits(th, band[p], lo, hi);
+    if (band_count<E>(h, n, lo, hi, lane) > 1) {
+        res.thr_key = (uint64_t)th << 32;
+        res.cut = SELECT_UNRESOLVED;
+    }
+}
+
 // word index of element idx of the float64 layout
 __device__ inline int64_t planar_word(int64_t idx) { return idx; }
 
@@ -240,7 +275,10 @@ __global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kerne
             continue;
         }
         SelectResult res;
-        if (!planar_trivial(k, N, res)) res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
+        if (!planar_trivial(k, N, res)) {
+            res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
+            band_resolve<E>(h, N, w.band, p, lane, res);
+        }
         if (lane == 0) {
             thr[i] = res.thr_key;
             cut[i] = res.cut;
@@ -337,7 +375,10 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
-        else if (!planar_trivial(k, M, res)) res = wave_select_hist_u32<16>(h, M, k, hist, lane, warm);
+        else if (!planar_trivial(k, M, res)) {
+            res = wave_select_hist_u32<16>(h, M, k, hist, lane, warm);
+            band_resolve<16>(h, M, w.band, p, lane, res);
+        }
         if (lane == 0) {
             w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
             w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
@@ -410,7 +451,10 @@ __global__ __launch_bounds__(64 * COLS) void select_cols_planar_wide_kernel(cons
     const uint64_t valid = planar_slot_valid<32>(M, lane);
     HistWarm warm{0, HIST_WARM_SHIFT0};
     SelectResult res;
-    if (!planar_trivial(k, M, res)) res = wave_select_hist_u32<32>(h, M, k, hist, lane, warm);
+    if (!planar_trivial(k, M, res)) {
+        res = wave_select_hist_u32<32>(h, M, k, hist, lane, warm);
+        band_resolve<32>(h, M, w.band, p, lane, res);
+    }
     if (lane == 0) {
         w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
         w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
@@ -441,12 +485,175 @@ __device__ inline double planar_exact_value(const double *__restrict__ feats, co
     return s;
 }
 
+// One row (DIR 0) or column (DIR 1) the selection kernels left unresolved, the general way: exact values for the
+// elements that share the winner's key (or, with approximate keys, lie inside its error band), then the bit-serial
+// selection over 64-bit keys.
+template <int DIR, int E>
+__device__ inline void fix_row_generic(const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
+                                       const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+                                       const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
+{
+    // the selection kernel left the high word the tied elements share: only those few need their exact value;
+    // every other element is ordered by its high word alone
+    const unsigned th = (unsigned)(thr[which] >> 32);
+    unsigned blo = 0u, bhi = 0u;
+    if (w.band != nullptr) band_limits(th, w.band[p], blo, bhi);
+    uint64_t key[E];
+    int idx[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        idx[e] = e * 64 + lane;
+        const int q = min(idx[e], len - 1);
+        const unsigned h = Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
+        uint64_t kx = (uint64_t)h << 32;
+        bool exact = th == 0u || h == th;
+        if (w.band != nullptr) {
+            // approximate keys: below the band certainly selected, above it certainly not, inside it exact values decide
+            kx = h < blo ? 0ull : ~0ull - 1ull;
+            exact = th == 0u || (h >= blo && h <= bhi);
+        }
+        if (exact)
+            kx = f64_key(DIR == 0 ? planar_exact_value(feats, norms, d, ds, win, which, q)
+                                  : planar_exact_value(feats, norms, d, ds, win, q, which));
+        key[e] = idx[e] < len ? kx : ~0ull;
+    }
+    const SelectResult res = wave_select_kth<E>(key, idx, len, k);
+    if (lane == 0) {
+        thr[which] = res.thr_key;
+        cut[which] = res.cut;
+    }
+    uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
+    if (bits) {
+        bits = DIR == 0 ? w.row_bits + ((int64_t)p * w.max_m + which) * E : w.col_word(p, which, 0);
+        const int64_t bstride = DIR == 0 ? 1 : w.max_n;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool on = (idx[e] < len) & ((key[e] < res.thr_key) | ((key[e] == res.thr_key) & (idx[e] <= res.cut)));
+            const uint64_t m = __ballot(on);
+            if (lane == e) mine = m;
+        }
+        if (lane < E) bits[lane * bstride] = mine;
+    }
+}
+
+// The same for approximate keys when few elements (<= 64) lie inside the error band, which is the rule: the wave works
+// on the band elements together.  Seven elements at a time, lane (g, kk) forms C[i + kk][j + kk] of element g with the
+// strip kernel's arithmetic (FMA chain over the rolled bins, all of a frame pair's loads in flight at once), lane g adds
+// the nine values in window order; every band element then counts the band elements that precede it in (exact value,
+// position) order, and the first k - (elements below the band) of them are selected.  Returns false if the row has to
+// go the general way.
+constexpr int FIX_MAXD = 16;
+struct FixSmem {
+    int pos[64];
+    unsigned long long key[64];
+    double cval[7 * 9];
+    unsigned char sel[64];
+};
+
+template <int DIR, int E>
+__device__ inline bool fix_row_band(FixSmem &sm, const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
+                                    const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+                                    const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
+{
+    const unsigned th = (unsigned)(thr[which] >> 32);
+    if (th == 0u || win != 9 || d > FIX_MAXD) return false;
+    unsigned blo, bhi;
+    band_limits(th, w.band[p], blo, bhi);
+    unsigned h[E];
+    int below = 0, n = 0;
+    int myidx[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int pos = e * 64 + lane;
+        const int q = min(pos, len - 1);
+        h[e] = Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
+        const bool valid = pos < len;
+        below += __popcll(__ballot(valid & (h[e] < blo)));
+        const bool in = valid & (h[e] >= blo) & (h[e] <= bhi);
+        const unsigned long long m = __ballot(in);
+        myidx[e] = in ? n + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+        n += __popcll(m);
+    }
+    const int need = k - below;
+    if (n > 64 || need < 1 || need > n) return false;      // (the last two cannot happen with a valid error band)
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (myidx[e] >= 0) sm.pos[myidx[e]] = e * 64 + lane;
+    __syncthreads();
+    for (int c0 = 0; c0 < n; c0 += 7) {
+        const int g = lane / 9, kk = lane - 9 * g, el = c0 + g;
+        if (lane < 63 && el < n) {
+            const int pos = sm.pos[el];
+            const int i = DIR == 0 ? which : pos, j = DIR == 0 ? pos : which;
+            const double *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
+            double xv[FIX_MAXD], yv[FIX_MAXD];
+#pragma unroll
+            for (int b = 0; b < FIX_MAXD; b++) {
+                int src = b - ds.shift;
+                if (src < 0) src += d;
+                xv[b] = b < d ? x[src] : 0.0;
+                yv[b] = b < d ? y[b] : 0.0;
+            }
+            const double nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
+            double acc = 0.0;
+#pragma unroll
+            for (int b = 0; b < FIX_MAXD; b++)
+                if (b < d) acc = fma(xv[b], yv[b], acc);
+            sm.cval[g * 9 + kk] = fmax(fma(-2.0, acc, nn), 0.0);
+        }
+        __syncthreads();
+        if (lane < 7 && c0 + lane < n) {
+            double s_ = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; q++) s_ += sm.cval[lane * 9 + q];
+            sm.key[c0 + lane] = f64_key(s_);
+        }
+        __syncthreads();
+    }
+    // rank of band element `lane` among the band elements: (exact key, position) order
+    int rank = 1;
+    unsigned long long mykey = 0;
+    int mypos = 0;
+    if (lane < n) { mykey = sm.key[lane]; mypos = sm.pos[lane]; }
+    for (int m = 0; m < n; m++) {
+        const unsigned long long km = sm.key[m];
+        const int pm = sm.pos[m];
+        rank += (km < mykey) | ((km == mykey) & (pm < mypos));
+    }
+    if (lane < n) sm.sel[lane] = rank <= need;
+    const unsigned long long last = __ballot(lane < n && rank == need);      // exactly one lane
+    const int ll = __ffsll((long long)last) - 1;
+    if (lane == ll) {
+        thr[which] = mykey;
+        cut[which] = 0x7fffffff;        // (ties in exact value inside the band were cut by position in the ranking above)
+    }
+    __syncthreads();
+    uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
+    if (bits) {
+        bits = DIR == 0 ? w.row_bits + ((int64_t)p * w.max_m + which) * E : w.col_word(p, which, 0);
+        const int64_t bstride = DIR == 0 ? 1 : w.max_n;
+        uint64_t mine = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool valid = e * 64 + lane < len;
+            const bool on = valid & ((h[e] < blo) | (myidx[e] >= 0 && sm.sel[myidx[e] & 63]));
+            const uint64_t m = __ballot(on);
+            if (lane == e) mine = m;
+        }
+        if (lane < E) bits[lane * bstride] = mine;
+    }
+    __syncthreads();
+    return true;
+}
+
 template <int DIR, int E = 16>
 __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
                                                                const double *__restrict__ norms, int d,
                                                                const acoss_pair_desc *__restrict__ descs, int win,
                                                                double kv, int k_mode, ThreshWork w, int groups)
 {
+    __shared__ FixSmem sm;
     const int p = blockIdx.x / groups, g = blockIdx.x % groups;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
@@ -462,40 +669,8 @@ __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *_
     while (todo) {
         const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
         todo &= todo - 1;
-        // the selection kernel left the high word the tied elements share: only those few need their exact value;
-        // every other element is ordered by its high word alone
-        const unsigned th = (unsigned)(thr[which] >> 32);
-        uint64_t key[E];
-        int idx[E];
-#pragma unroll
-        for (int e = 0; e < E; e++) {
-            idx[e] = e * 64 + lane;
-            const int q = min(idx[e], len - 1);
-            const unsigned h = Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
-            uint64_t kx = (uint64_t)h << 32;
-            if (th == 0u || h == th)
-                kx = f64_key(DIR == 0 ? planar_exact_value(feats, norms, d, ds, win, which, q)
-                                      : planar_exact_value(feats, norms, d, ds, win, q, which));
-            key[e] = idx[e] < len ? kx : ~0ull;
-        }
-        const SelectResult res = wave_select_kth<E>(key, idx, len, k);
-        if (lane == 0) {
-            thr[which] = res.thr_key;
-            cut[which] = res.cut;
-        }
-        uint64_t *bits = DIR == 0 ? w.row_bits : w.col_bits;
-        if (bits) {
-            bits = DIR == 0 ? w.row_bits + ((int64_t)p * w.max_m + which) * E : w.col_word(p, which, 0);
-            const int64_t bstride = DIR == 0 ? 1 : w.max_n;
-            uint64_t mine = 0;
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const bool on = (idx[e] < len) & ((key[e] < res.thr_key) | ((key[e] == res.thr_key) & (idx[e] <= res.cut)));
-                const uint64_t m = __ballot(on);
-                if (lane == e) mine = m;
-            }
-            if (lane < E) bits[lane * bstride] = mine;
-        }
+        if (w.band != nullptr && fix_row_band<DIR, E>(sm, Thi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) continue;
+        fix_row_generic<DIR, E>(Thi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
     }
 }
 
@@ -512,7 +687,7 @@ static void kappa_mode_planar(double kappa, double &kv, int &mode)
 static int run_planar(int probe, const uint32_t *planes, const double *feats, const double *norms, int d,
                       const acoss_pair_desc *descs, int K, int win,
                       int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes,
-                      hipStream_t st)
+                      hipStream_t st, const float *band = nullptr)
 {
     if (!planes || !feats || !norms || d < 1 || !descs || !work || K < 0 || win < 1 || max_nx < win || max_ny < win || kappa < 0.0) {
         set_error("mask_bits_planar: bad argument");
@@ -528,6 +703,7 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         return ACOSS_EINVAL;
     }
     ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    w.band = band;
     if (K == 0) return ACOSS_OK;
     double kv;
     int mode;
@@ -612,6 +788,16 @@ int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, co
     if (!bits) { set_error("mask_bits_planar_batch: bad argument"); return ACOSS_EINVAL; }
     return run_planar(0, planes, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, work_bytes,
                       (hipStream_t)stream);
+}
+
+int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, const double *feats, const double *norms, int d,
+                                   const acoss_pair_desc *descs, int K, int win,
+                                   int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
+                                   size_t work_bytes, void *stream)
+{
+    if (!bits || !band) { set_error("mask_bits_planar32_batch: bad argument"); return ACOSS_EINVAL; }
+    return run_planar(0, keys, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, work_bytes,
+                      (hipStream_t)stream, band);
 }
 
 // development probe (not part of the public ABI): 1 = row loads only, 2 = row selection kernel alone,

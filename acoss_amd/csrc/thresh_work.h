@@ -20,6 +20,9 @@ struct ThreshWork {
     uint64_t *col_bits;  // [K][wpr][max_n]: word-major, so that word e of 64 neighbouring columns is one 512-byte run
                          // (what the transposing combine kernel reads); column j's word e = col_word(p, j, e)
     int wpr;
+    // float32-approximate keys (strip32_kernels.hip): per pair, twice the error bound of the approximate values; a row or
+    // column is resolved only if no other key lies within that distance of its k-th smallest.  nullptr: exact high words.
+    const float *band;
     __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };
 
@@ -44,6 +47,7 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
     w.col_cut = w.row_cut + (size_t)K * max_m;
     w.row_bits = nullptr;
     w.col_bits = nullptr;
+    w.band = nullptr;
     w.wpr = mask_bits_words(max_m, max_n);
     if (with_bits) {
         uintptr_t a = (uintptr_t)(w.col_cut + (size_t)K * max_n);

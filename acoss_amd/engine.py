@@ -65,6 +65,23 @@ class DeviceCorpus(object):
     def lengths(self):
         return np.diff(self.frame_off)
 
+    def song_wmax(self, win):
+        """Per song, the largest sum of squared frame norms over `win` consecutive frames (host float64): the scale of
+        the error bound of the float32-approximate windowed sums (crp_planar32)."""
+        cache = getattr(self, "_wmax", None)
+        if cache is None or cache[0] != win:
+            nrm = self.norms.cpu().numpy().astype(np.float64)
+            out = np.zeros(self.n_songs)
+            for s_ in range(self.n_songs):
+                a, b = int(self.frame_off[s_]), int(self.frame_off[s_ + 1])
+                if b - a >= win:
+                    c = np.concatenate([[0.0], np.cumsum(nrm[a:b])])
+                    out[s_] = float(np.max(c[win:] - c[:-win])) * (1.0 + 1e-12)
+                else:
+                    out[s_] = float(nrm[a:b].sum())
+            self._wmax = (win, out)
+        return self._wmax[1]
+
 
 class PairBatch(object):
     """The plan of one launch batch: K pair descriptors on host and device."""
@@ -238,6 +255,36 @@ def crp_planar32(corpus, batch, xp32, out=None):
     check(lib.acoss_crp_planar32_batch(_ptr(xp32), _ptr(f32), _ptr(n32), corpus.d, _ptr(batch.descs_dev), batch.K,
                                        batch.win, batch.max_nx, batch.max_ny, _ptr(out), _stream()), "crp_planar32_batch")
     return out
+
+
+PLANAR32_BOUND = 41.0 * 2.0 ** -24      # |approx - exact| <= this x (window sums of squared norms); analysis: 39.x
+
+
+def planar32_band(corpus, batch):
+    """Per pair of the batch, twice the error bound of crp_planar32's values, rounded up to float32 (device tensor)."""
+    w = corpus.song_wmax(batch.win)
+    sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
+    band = 2.0 * PLANAR32_BOUND * (w[sx] + w[sy])
+    b32 = band.astype(np.float32)
+    b32 = np.where(b32.astype(np.float64) < band, np.nextafter(b32, np.float32(np.inf)), b32).astype(np.float32)
+    return torch.from_numpy(np.ascontiguousarray(b32)).to(corpus.device)
+
+
+def mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=True, out=None, work=None):
+    """mask_bits_planar() on the float32-approximate keys of crp_planar32(): rows / columns with another value inside the
+    error band of their k-th smallest are finished exactly in float64; identical masks."""
+    lib = _lib.load()
+    max_m = batch.max_nx - batch.win + 1
+    if out is None:
+        out = torch.zeros(max(batch.K * max_m * bits_words(batch), 1), dtype=torch.int64, device=keys.device)
+    need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=keys.device)
+    check(lib.acoss_mask_bits_planar32_batch(_ptr(keys), _ptr(band), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                             _ptr(batch.descs_dev), batch.K, batch.win,
+                                             batch.max_nx, batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out),
+                                             _ptr(work), work.numel(), _stream()), "mask_bits_planar32_batch")
+    return out, work
 
 
 def planar_elems(batch):

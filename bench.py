@@ -45,7 +45,7 @@ def parse():
                     help="pairs per launch batch and GPU (4096 x 3.9 MB of key high words = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--path", choices=("fast", "fast_f64", "staged"), default="fast",
+    ap.add_argument("--path", choices=("fast", "fast32", "fast_f64", "staged"), default="fast",
                     help="fast: fused CSM+sliding kernel writing two uint32 planes, selection on the high words (the "
                          "product path); fast_f64: the same with a float64 matrix in between; staged: one kernel per "
                          "reference function")
@@ -58,6 +58,7 @@ def parse():
 
 
 STAGES = {"fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
+          "fast32": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "fast_f64": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
 
@@ -80,7 +81,13 @@ class Runner(object):
         self.overlap = False
         # "fast": T leaves the strip kernel as two uint32 planes (key high / low words) and the selections read
         # only the high-word plane; "fast_f64": T as float64, selections read 8 bytes per element
+        # "fast32": the strip kernel computes a float32 approximation (float32 keys); rows / columns whose k-th smallest
+        # has another value inside the error band are finished in float64: identical masks and scores
+        self.p32 = path == "fast32"
+        if self.p32:
+            path = self.path = "fast"
         self.planar = path == "fast" and all(engine.planar_supported(corpus, b) for b in batches)
+        self.p32 = self.p32 and self.planar
         if path == "fast_f64":
             path = self.path = "fast"
         self.corpus, self.m, self.kappa = corpus, m, kappa
@@ -102,6 +109,10 @@ class Runner(object):
         else:
             need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
         self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        if self.p32:
+            self.xp32 = torch.empty(self.xp.numel(), dtype=torch.float32, device=dev)
+            self.bands = [engine.planar32_band(corpus, b) for b in batches]
+            engine.float32_copy(corpus)
         # --overlap: the alignment sweep (latency-bound: 992 serial row steps, one wave per pair, 124 KB of mask per
         # pair) of batch b runs on a second HIP stream while the main stream already builds batch b + 1 (two mask
         # buffers, events both ways)
@@ -132,7 +143,12 @@ class Runner(object):
                 best = 1e9
                 for rep in range(3):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record(); engine.crp_planar(corpus, b0, self.xp, out=planes); e1.record()
+                    e0.record()
+                    if self.p32:
+                        engine.crp_planar32(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp32), out=planes)
+                    else:
+                        engine.crp_planar(corpus, b0, self.xp, out=planes)
+                    e1.record()
                     torch.cuda.synchronize()
                     if rep:
                         best = min(best, e0.elapsed_time(e1))
@@ -154,7 +170,8 @@ class Runner(object):
         self.csm_bytes = [float(np.sum(es * (x * y + corpus.d * (x + y)))) for x, y in zip(nx, ny)]
         # the fast path's strip kernel writes 4 bytes per cell (key high words), the float64 form 8
         cell = 4.0 if self.planar else 8.0
-        self.crp_bytes = [float(np.sum(cell * (x - m + 1) * (y - m + 1) + es * corpus.d * (x + y))) for x, y in zip(nx, ny)]
+        fes = 4 if self.p32 else es
+        self.crp_bytes = [float(np.sum(cell * (x - m + 1) * (y - m + 1) + fes * corpus.d * (x + y))) for x, y in zip(nx, ny)]
 
     def step(self, i, scores_out, ev=None):
         e = self.engine
@@ -189,9 +206,15 @@ class Runner(object):
         e.oti(self.corpus, b)
         mark(1)
         if self.path == "fast":
-            e.pack_x(self.corpus, b, out=self.xp)
+            if self.p32:
+                e.pack_x32(self.corpus, b, out=self.xp32)
+            else:
+                e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            if self.planar:
+            if self.p32:
+                planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
+                e.crp_planar32(self.corpus, b, self.xp32, out=planes)
+            elif self.planar:
                 planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
                 e.crp_planar(self.corpus, b, self.xp, out=planes)
             else:
@@ -202,7 +225,9 @@ class Runner(object):
             e.sliding(self.C, b, out=self.S)
         mark(3)
         if self.path == "fast":
-            if self.planar:
+            if self.p32:
+                e.mask_bits_planar32(planes, self.bands[i], self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
+            elif self.planar:
                 e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
             else:
                 e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
@@ -248,7 +273,7 @@ def main():
     n_steps = args.warmup + args.steps
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
     step_idx = [mine[(np.arange(P) + s * P) % len(mine)] for s in range(n_steps)]
-    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev, pitch_align=32 if args.path == "fast" else 16) for ix in step_idx]
+    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev, pitch_align=32 if args.path in ("fast", "fast32") else 16) for ix in step_idx]
     runner = Runner(corpus, batches, m, kappa, args.path, overlap=args.overlap)
     scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
@@ -293,7 +318,7 @@ def main():
                                           for s in range(args.warmup, n_steps)])) for k in range(5)}
     # dominant HBM-bound kernel of the path: the cross-similarity kernel (fused with the sliding
     # window in the fast path, materialising the CSM in the staged path)
-    if args.path in ("fast", "fast_f64"):
+    if args.path in ("fast", "fast32", "fast_f64"):
         kname, kms, kbytes = "crp_strip_kernel<12,9> (CRPUtils.py:67 + :24 fused, f64 MFMA)", stage_ms["crp"], runner.crp_bytes
     else:
         kname, kms, kbytes = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
@@ -314,11 +339,14 @@ def main():
             traffic_src = "profiles/r01_final_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
     if runner.planar:
         kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
+    if runner.p32:
+        kname = "crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA approximation, float32 keys out: 4 B / cell; exact f64 refinement in select_fix_planar_kernel)"
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
         "value": round(value, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32 filter + f64 exact refinement (results identical to f64)" if runner.p32 else "f64",
         "data": "synthetic",
         "config": {"workload": "synthetic %d songs x %d frames x 12-bin HPCP (f64), Serra09 chroma_qmax "
                                "m=9 kappa=0.095 OTI, %d pairs/step/GPU of the %d-pair job"
@@ -332,7 +360,7 @@ def main():
                      "bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 4)},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
-    if rank == 0 and args.path in ("fast", "fast_f64"):
+    if rank == 0 and args.path in ("fast", "fast32", "fast_f64"):
         # get_csm as an API (the kernel the north star names) on the same batch, outside the timed
         # region, reported beside the path's own dominant kernel: the plain VALU kernel and the
         # persistent matrix-core strip kernel (bit-identical outputs)
@@ -412,6 +440,31 @@ def main():
                 "sample": "%d x %d calls of the reference's qmax_c (SequenceAlignment.c:113, -Ofast) on %dx%d masks, D zeroed per "
                           "call" % (reps, n_dp, Mn, Mn),
                 "identical_to_gpu": bool(np.array_equal(np.array(q_ref) / denom, gpu_q[:n_dp]))}
+    if rank == 0 and world == 1 and args.path == "fast" and runner.planar and not os.environ.get("ACOSS_BENCH_NO_FAST32"):
+        # beside the float64 line above: the same steps with the float32-filter form of the strip kernel (`--path fast32`);
+        # its scores must equal the float64 path's on every pair of the timed steps
+        last = scores[args.warmup:].clone()
+        del runner, events
+        engine.release_scratch()
+        r32 = Runner(corpus, batches, m, kappa, "fast32", overlap=False)
+        s32 = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
+        ev32 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
+        for s_ in range(args.warmup):
+            r32.step(s_, s32[s_])
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s_ in range(args.warmup, n_steps):
+            r32.step(s_, s32[s_], ev32[s_])
+        h32 = s32[args.warmup:].reshape(-1).cpu().numpy()
+        torch.cuda.synchronize()
+        el32 = time.perf_counter() - t0
+        names = STAGES["fast32"]
+        out["fast32"] = {"value": round(args.steps * P / el32, 1), "unit": "pair-scores/s", "ms_per_step": round(1e3 * el32 / args.steps, 3),
+                         "dtype": "f32 filter + f64 exact refinement",
+                         "stage_ms": {names[k]: round(float(np.mean([ev32[s_][k].elapsed_time(ev32[s_][k + 1])
+                                                                       for s_ in range(args.warmup, n_steps)])), 4) for k in range(5)},
+                         "scores_identical_to_f64_path": bool(torch.equal(s32[args.warmup:], last)),
+                         "note": "crp_strip32_kernel + error-band check + float64 refinement (DESIGN.md section 4); same steps, same pairs"}
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

@@ -256,6 +256,15 @@ int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, co
                                  const acoss_pair_desc *descs, int K, int win,
                                  int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
                                  void *work, size_t work_bytes, void *stream);
+/* acoss_mask_bits_planar_batch on the float32-approximate keys of acoss_crp_planar32_batch.  band[p] = twice the error
+ * bound of pair p's approximate values (2 * 40 * 2^-24 * (largest window sum of squared norms of song x + of song y),
+ * rounded up).  A row / column whose k-th smallest approximate value has another value within band[p] is finished
+ * in float64: the values inside the band are recomputed exactly from feats / norms (the float64 corpus), the rest is
+ * decided by the approximation.  The masks equal acoss_mask_bits_planar_batch's bit for bit. */
+int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, const double *feats, const double *norms,
+                                   int d, const acoss_pair_desc *descs, int K, int win,
+                                   int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
+                                   void *work, size_t work_bytes, void *stream);
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win,
                            int max_nx, int max_ny, int boundary, const acoss_align_params *params,
                            float *scores, void *stream);

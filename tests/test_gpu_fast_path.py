@@ -355,3 +355,61 @@ def test_wide_forms_up_to_2048(eng, orc):
     for t, (i, j) in enumerate(pairs[[0, 3]]):
         q, dm = orc.serra09_pair(feats[off[i]:off[i + 1]], gc[i], feats[off[j]:off[j + 1]], gc[j])
         assert got["qmax"][t] == q and got["dmax"][t] == dm, (i, j)
+
+
+def test_float32_approximate_keys_give_identical_masks(eng, golden):
+    """crp_planar32 (float32 windowed sums, bound 41 * 2^-24 * window norm sums) + mask_bits_planar32 (error-band check,
+    exact float64 refinement inside the band) == mask_bits on the float64 matrix, bit for bit: golden 1000-frame pairs,
+    ragged small pairs, crafted exact ties and 1e-11 perturbations (everything inside the band), 1033 .. 2056-frame songs;
+    the approximation stays inside its bound."""
+    import torch
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    rng = np.random.default_rng(5)
+    pat7, pat5 = rng.random((7, 12)) + 0.1, rng.random((5, 12)) + 0.1
+    A = np.tile(pat7, (30, 1))[:200]
+    Bs = np.tile(pat5, (31, 1))[:151]
+    C = A + 1e-11 * rng.random(A.shape)
+    Dn = Bs + 1e-11 * rng.random(Bs.shape)
+    tie_feats = np.concatenate([A, Bs, C, Dn])
+    tie_off = np.cumsum([0, len(A), len(Bs), len(C), len(Dn)]).astype(np.int64)
+    tie_gc = np.stack([x.sum(0) / x.sum(0).max() for x in (A, Bs, C, Dn)])
+    wl = iter([2056, 1033, 300, 1500])
+    wide = synth.make_corpus(2, 2, seed=611, lengths=lambda r: next(wl))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"], (0.095, 0.5, 3, 0)),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32), (0.095, 0.5, 3, 0)),
+             (tie_feats, tie_off, tie_gc, np.array([(i, j) for i in range(4) for j in range(4)], dtype=np.int32), (0.095,)),
+             (wide.feats, wide.frame_off, wide.gchroma, np.array([(0, 1), (1, 0), (2, 3), (3, 0), (0, 0)], dtype=np.int32), (0.095,))]
+    for ci, (feats, off, gc, pairs, kappas) in enumerate(cases):
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        for align in (32, 1):
+            batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+            eng.oti(corpus, batch)
+            T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+            keys = eng.crp_planar32(corpus, batch, eng.pack_x32(corpus, batch))
+            band = eng.planar32_band(corpus, batch)
+            # the approximation against its bound (per pair: band / 2)
+            Th, Kh, bh = T.cpu().numpy(), keys.cpu().numpy().view(np.uint32), band.cpu().numpy().astype(np.float64)
+            for p in range(batch.K):
+                d = batch.descs[p]
+                M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
+                idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+                approx = (Kh[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
+                assert np.all(Kh[idx] >> 31 == 1) and np.max(np.abs(approx - Th[idx])) <= bh[p] / 2, (ci, p)
+            planes = eng.crp_planar(corpus, batch, eng.pack_x(corpus, batch)) if ci < 3 else None
+            for mutual in (True, False):
+                for kappa in kappas:
+                    got, _ = eng.mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=mutual)
+                    if planes is not None:
+                        want, _ = eng.mask_bits_planar(planes, corpus, batch, kappa, mutual=mutual)
+                        for p in range(batch.K):
+                            assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (ci, align, mutual, kappa, p)
+                    else:
+                        B = eng.binarize(T, batch, kappa, mutual=mutual)
+                        for p in range(batch.K):
+                            d = batch.descs[p]
+                            M, N = int(batch.M[p]), int(batch.N[p])
+                            want = B[int(d["crp_off"]):int(d["crp_off"]) + M * int(d["crp_pitch"])].cpu().numpy().reshape(M, -1)[:, :N]
+                            assert np.array_equal(eng.unpack_mask_bits(got, batch, p), want), (ci, align, mutual, kappa, p)
