@@ -111,7 +111,7 @@ __device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int 
         if (m1 == 0) {
             hist_clear(hist, lane);
             if (kind != PREDICTED) return res;
-            warm.shift = min(warm.shift + 1, HIST_WARM_SHIFT_MAX);
+            warm.shift = min(warm.shift + 1, HIST_WARM_SHIFT_MAX + 3);
             kind = FULL;
             continue;
         }
@@ -183,13 +183,15 @@ __device__ inline void band_limits(unsigned th, float band, unsigned &lo, unsign
     hi = (__float_as_uint(h) | 0x80000000u) + 1u;
 }
 
-// number of the wave's n keys inside [lo, hi] (wave-uniform)
+// number of the wave's keys inside [lo, hi] (wave-uniform).  Padding slots (positions >= n repeat a real element) are
+// counted too: that can only turn a resolved row into one for the fix-up pass, never the other way round.
 template <int E>
-__device__ inline int band_count(const unsigned (&h)[E], int n, unsigned lo, unsigned hi, int lane)
+__device__ inline int band_count(const unsigned (&h)[E], unsigned lo, unsigned hi)
 {
+    const unsigned width = hi - lo;
     int c = 0;
 #pragma unroll
-    for (int e = 0; e < E; e++) c += __popcll(__ballot((h[e] >= lo) & (h[e] <= hi) & (e * 64 + lane < n)));
+    for (int e = 0; e < E; e++) c += __popcll(__ballot((h[e] - lo) <= width));
     return c;
 }
 
@@ -201,7 +203,7 @@ __device__ inline void band_resolve(const unsigned (&h)[E], int n, const float *
     const unsigned th = (unsigned)(res.thr_key >> 32);
     unsigned lo, hi;
     band_limits(th, band[p], lo, hi);
-    if (band_count<E>(h, n, lo, hi, lane) > 1) {
+    if (band_count<E>(h, lo, hi) > 1) {
         res.thr_key = (uint64_t)th << 32;
         res.cut = SELECT_UNRESOLVED;
     }
@@ -247,7 +249,8 @@ __global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kerne
     int *cut = w.row_cut + (int64_t)p * w.max_m;
     unsigned *hist = hist_all + wave * HIST_WORDS;
     hist_clear(hist, lane);
-    HistWarm warm{0, HIST_WARM_SHIFT0};
+    // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
+    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
     const uint64_t valid = planar_slot_valid<E>(N, lane);
     const bool wide = N > (E - 1) * 64;       // wave-uniform: only the last slot can run past the row
     for (int i = r0; i < r1; i++) {
@@ -371,7 +374,8 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     hist_clear(hist, lane);
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<16>(M, lane);
-    HistWarm warm{0, HIST_WARM_SHIFT0};
+    // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
+    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
@@ -449,7 +453,8 @@ __global__ __launch_bounds__(64 * COLS) void select_cols_planar_wide_kernel(cons
     hist_clear(hist, lane);
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<32>(M, lane);
-    HistWarm warm{0, HIST_WARM_SHIFT0};
+    // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
+    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
     SelectResult res;
     if (!planar_trivial(k, M, res)) {
         res = wave_select_hist_u32<32>(h, M, k, hist, lane, warm);
