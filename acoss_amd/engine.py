@@ -6,6 +6,7 @@ torch.distributed.  All arithmetic happens in libacoss_mi355x.so; tensors cross 
 raw device pointers.
 """
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -66,11 +67,12 @@ class DeviceCorpus(object):
         return np.diff(self.frame_off)
 
     def song_wmax(self, win):
-        """Per song, the largest sum of squared frame norms over `win` consecutive frames (host float64): the scale of
-        the error bound of the float32-approximate windowed sums (crp_planar32)."""
+        """Per song, the largest sum of squared (centred: float32_copy) frame norms over `win` consecutive frames (host
+        float64): the scale of the error bound of the float32-approximate windowed sums (crp_planar32)."""
         cache = getattr(self, "_wmax", None)
         if cache is None or cache[0] != win:
-            nrm = self.norms.cpu().numpy().astype(np.float64)
+            float32_copy(self)
+            nrm = self._f32_norms64.astype(np.float64)
             out = np.zeros(self.n_songs)
             for s_ in range(self.n_songs):
                 a, b = int(self.frame_off[s_]), int(self.frame_off[s_ + 1])
@@ -226,10 +228,16 @@ def crp_planar(corpus, batch, xp, out=None):
 
 
 def float32_copy(corpus):
-    """(features, squared norms) of a float64 corpus rounded to float32, cached on the corpus: the operands of the
-    approximate strip kernel (crp_planar32)."""
+    """(features, squared norms) of a float64 corpus, centred and rounded to float32, cached on the corpus: the operands
+    of the approximate strip kernel (crp_planar32).  Every entry has the corpus mean subtracted first: distances between
+    frames do not change (the shift is the same in every bin, so it commutes with the OTI rotation), but the squared
+    norms -- the scale of the float32 error bound -- shrink to the variance part (about a third for chroma)."""
     if getattr(corpus, "_f32", None) is None:
-        corpus._f32 = (corpus.feats.to(torch.float32), corpus.norms.to(torch.float32))
+        mu = corpus.feats.mean()
+        centred = corpus.feats - mu
+        n64 = (centred * centred).sum(1)
+        corpus._f32 = (centred.to(torch.float32), n64.to(torch.float32))
+        corpus._f32_norms64 = n64.cpu().numpy()
     return corpus._f32
 
 
@@ -257,7 +265,7 @@ def crp_planar32(corpus, batch, xp32, out=None):
     return out
 
 
-PLANAR32_BOUND = 41.0 * 2.0 ** -24      # |approx - exact| <= this x (window sums of squared norms); analysis: 39.x
+PLANAR32_BOUND = 48.0 * 2.0 ** -24      # |approx - exact| <= this x (window sums of squared norms); derivation in DESIGN.md section 4
 
 
 def planar32_band(corpus, batch):
@@ -486,7 +494,13 @@ def release_scratch():
     torch.cuda.empty_cache()
 
 
-def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None):
+def planar32_default():
+    """Whether the chain uses the float32-filter form of the strip kernel (crp_planar32 + mask_bits_planar32: identical
+    masks and scores, ~9 % faster end to end) when the caller does not say.  ACOSS_PLANAR32=1 turns it on."""
+    return os.environ.get("ACOSS_PLANAR32", "0") not in ("0", "", "false", "no")
+
+
+def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None, approx32=None):
     """
     Serra09.py:166-175 for every pair, fast path: oti -> pack_x -> crp (fused CSM + sliding window,
     squared) -> mutual binarise -> qmax [-> dmax on qmax's boundary].  Falls back to the staged
@@ -510,7 +524,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     if cls.min() != cls.max():
         for c in np.unique(cls):
             part = np.flatnonzero(cls == c)
-            res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs)
+            res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs, approx32)
             for k in want:
                 out[k][part] = res[k]
         return out
@@ -525,6 +539,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         if do_oti:
             oti(corpus, batch)
         planar = planar_supported(corpus, batch)
+        use32 = planar and (planar32_default() if approx32 is None else bool(approx32))
         # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
         xp = pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
         T = _scratch("T", (batch.total_crp + 1) // 2 + 1 if planar else max(batch.total_crp, 1), torch.float64, corpus.device)
@@ -544,7 +559,11 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                 if kind in want:
                     out[kind][lo:lo + len(sel)] = align(kind, B, mats, **kw).cpu().numpy().astype(np.float64) / denom
             continue
-        if planar:
+        if use32:
+            xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
+            keys = crp_planar32(corpus, batch, xp32, out=T.view(torch.int32)[:planar_elems(batch)])
+            bits, work = mask_bits_planar32(keys, planar32_band(corpus, batch), corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
+        elif planar:
             planes = crp_planar(corpus, batch, xp, out=T.view(torch.int32)[:planar_elems(batch)])
             bits, work = mask_bits_planar(planes, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
         else:

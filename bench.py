@@ -440,7 +440,7 @@ def main():
                 "sample": "%d x %d calls of the reference's qmax_c (SequenceAlignment.c:113, -Ofast) on %dx%d masks, D zeroed per "
                           "call" % (reps, n_dp, Mn, Mn),
                 "identical_to_gpu": bool(np.array_equal(np.array(q_ref) / denom, gpu_q[:n_dp]))}
-    if rank == 0 and world == 1 and args.path == "fast" and runner.planar and os.environ.get("ACOSS_BENCH_FAST32"):
+    if rank == 0 and world == 1 and args.path == "fast" and runner.planar and not os.environ.get("ACOSS_BENCH_NO_FAST32"):
         # beside the float64 line above: the same steps with the float32-filter form of the strip kernel (`--path fast32`);
         # its scores must equal the float64 path's on every pair of the timed steps
         last = scores[args.warmup:].clone()

@@ -358,7 +358,7 @@ def test_wide_forms_up_to_2048(eng, orc):
 
 
 def test_float32_approximate_keys_give_identical_masks(eng, golden):
-    """crp_planar32 (float32 windowed sums, bound 41 * 2^-24 * window norm sums) + mask_bits_planar32 (error-band check,
+    """crp_planar32 (float32 windowed sums, bound 48 * 2^-24 * window norm sums) + mask_bits_planar32 (error-band check,
     exact float64 refinement inside the band) == mask_bits on the float64 matrix, bit for bit: golden 1000-frame pairs,
     ragged small pairs, crafted exact ties and 1e-11 perturbations (everything inside the band), 1033 .. 2056-frame songs;
     the approximation stays inside its bound."""

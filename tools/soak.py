@@ -18,7 +18,7 @@ allp = synth.all_pairs(ch.n_songs)
 pairs = allp[rng.permutation(len(allp))[:n_pairs]]
 pairs = np.where(rng.random((len(pairs), 1)) < 0.5, pairs, pairs[:, ::-1]).astype(np.int32)      # both orientations
 t0 = time.time()
-got = engine.serra09_scores(corpus, pairs)
+got = engine.serra09_scores(corpus, pairs, approx32=bool(os.environ.get("ACOSS_PLANAR32")) or None)
 t1 = time.time()
 threads = min(os.cpu_count() or 1, 16)
 q, d, _ = oracle.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=threads)
