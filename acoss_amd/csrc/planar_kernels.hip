@@ -175,9 +175,11 @@ __device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int 
 // ---- float32-approximate keys: the error band around a threshold ----------------------------------------------
 // Keys are float32 bit patterns (values >= +0) with the sign bit set.  [lo, hi] = the keys of the values within `band`
 // of the value of key th, widened by one ulp each way for the rounding of the two float operations.
-__device__ inline void band_limits(unsigned th, float band, unsigned &lo, unsigned &hi)
+// band = base + slope * value: twice the error bound of a value of that size (the caller's two floats per pair).
+__device__ inline void band_limits(unsigned th, const float *pair_band, unsigned &lo, unsigned &hi)
 {
     const float a = __uint_as_float(th & 0x7fffffffu);
+    const float band = fmaf(pair_band[1], a, pair_band[0]);
     const float l = a - band, h = a + band;
     lo = l > 0.0f ? (__float_as_uint(l) | 0x80000000u) - 1u : 0x80000000u;
     hi = (__float_as_uint(h) | 0x80000000u) + 1u;
@@ -202,7 +204,7 @@ __device__ inline void band_resolve(const unsigned (&h)[E], int n, const float *
     if (band == nullptr || res.cut == SELECT_UNRESOLVED || res.cut < 0 || res.thr_key == ~0ull) return;
     const unsigned th = (unsigned)(res.thr_key >> 32);
     unsigned lo, hi;
-    band_limits(th, band[p], lo, hi);
+    band_limits(th, band + 2 * p, lo, hi);
     if (band_count<E>(h, lo, hi) > 1) {
         res.thr_key = (uint64_t)th << 32;
         res.cut = SELECT_UNRESOLVED;
@@ -502,7 +504,7 @@ __device__ inline void fix_row_generic(const uint32_t *__restrict__ Thi, const d
     // every other element is ordered by its high word alone
     const unsigned th = (unsigned)(thr[which] >> 32);
     unsigned blo = 0u, bhi = 0u;
-    if (w.band != nullptr) band_limits(th, w.band[p], blo, bhi);
+    if (w.band != nullptr) band_limits(th, w.band + 2 * p, blo, bhi);
     uint64_t key[E];
     int idx[E];
 #pragma unroll
@@ -564,7 +566,7 @@ __device__ inline bool fix_row_band(FixSmem &sm, const uint32_t *__restrict__ Th
     const unsigned th = (unsigned)(thr[which] >> 32);
     if (th == 0u || win != 9 || d > FIX_MAXD) return false;
     unsigned blo, bhi;
-    band_limits(th, w.band[p], blo, bhi);
+    band_limits(th, w.band + 2 * p, blo, bhi);
     unsigned h[E];
     int below = 0, n = 0;
     int myidx[E];

@@ -20,8 +20,9 @@ struct ThreshWork {
     uint64_t *col_bits;  // [K][wpr][max_n]: word-major, so that word e of 64 neighbouring columns is one 512-byte run
                          // (what the transposing combine kernel reads); column j's word e = col_word(p, j, e)
     int wpr;
-    // float32-approximate keys (strip32_kernels.hip): per pair, twice the error bound of the approximate values; a row or
-    // column is resolved only if no other key lies within that distance of its k-th smallest.  nullptr: exact high words.
+    // float32-approximate keys (strip32_kernels.hip): per pair two floats (base, slope): twice the error bound of an
+    // approximate value v is base + slope * v; a row or column is resolved only if no other key lies within that distance
+    // of its k-th smallest.  nullptr: exact high words.
     const float *band;
     __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };

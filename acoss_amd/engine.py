@@ -265,17 +265,25 @@ def crp_planar32(corpus, batch, xp32, out=None):
     return out
 
 
-PLANAR32_BOUND = 48.0 * 2.0 ** -24      # |approx - exact| <= this x (window sums of squared norms); derivation in DESIGN.md section 4
+# |approx - exact| <= PLANAR32_BOUND_W * (window sums of squared norms) + PLANAR32_BOUND_T * exact.  Analysis with
+# round-to-nearest accumulation: 16 u W + 9 u T; the constants leave room for an accumulation that
+# does not round to nearest inside the matrix core.
+PLANAR32_BOUND_W = 24.0 * 2.0 ** -24
+PLANAR32_BOUND_T = 11.0 * 2.0 ** -24
 
 
 def planar32_band(corpus, batch):
-    """Per pair of the batch, twice the error bound of crp_planar32's values, rounded up to float32 (device tensor)."""
+    """Per pair of the batch two float32 (base, slope): twice the error bound of a value v of crp_planar32 is
+    base + slope * v, both rounded up (device tensor of 2 K floats)."""
     w = corpus.song_wmax(batch.win)
     sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
-    band = 2.0 * PLANAR32_BOUND * (w[sx] + w[sy])
+    up = 1.0 + 2.0 ** -10        # covers the float32 rounding of base, slope and of base + slope * v in the kernels
+    band = np.empty((batch.K, 2), dtype=np.float64)
+    band[:, 0] = 2.0 * PLANAR32_BOUND_W * (w[sx] + w[sy]) * up
+    band[:, 1] = 2.0 * PLANAR32_BOUND_T * up
     b32 = band.astype(np.float32)
     b32 = np.where(b32.astype(np.float64) < band, np.nextafter(b32, np.float32(np.inf)), b32).astype(np.float32)
-    return torch.from_numpy(np.ascontiguousarray(b32)).to(corpus.device)
+    return torch.from_numpy(np.ascontiguousarray(b32.reshape(-1))).to(corpus.device)
 
 
 def mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=True, out=None, work=None):

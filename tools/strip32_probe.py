@@ -20,14 +20,14 @@ for align in (() if os.environ.get("ACOSS_STRIP32_NOSTORE") else (32, 1)):
     T = engine.crp(rc, b, engine.pack_x(rc, b)).cpu().numpy()
     A = engine.crp_planar32(rc, b, engine.pack_x32(rc, b)).cpu().numpy().view(np.uint32)
     worst = 0.0
-    half = engine.planar32_band(rc, b).cpu().numpy().astype(np.float64) / 2      # the bound per pair
+    bnd = engine.planar32_band(rc, b).cpu().numpy().astype(np.float64).reshape(-1, 2) / 2      # the bound per pair: base + slope * value
     for p in range(b.K):
         d = b.descs[p]
         Mm, Nn = int(d["nx"]) - 8, int(d["ny"]) - 8
         idx = (int(d["crp_off"]) + np.arange(Mm)[:, None] * int(d["crp_pitch"]) + np.arange(Nn)[None, :]).astype(np.int64)
         approx = (A[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
         assert np.all(A[idx] >> 31 == 1)
-        worst = max(worst, float(np.max(np.abs(approx - T[idx])) / half[p]))
+        worst = max(worst, float(np.max(np.abs(approx - T[idx]) / (bnd[p, 0] + bnd[p, 1] * T[idx]))))
     print("pitch_align %d: max |approx - exact| / bound = %.4f over %d pairs" % (align, worst, b.K))
 batch = engine.PairBatch(corpus.frame_off, allp[np.arange(K) % len(allp)], 9, corpus.device, pitch_align=32)
 engine.oti(corpus, batch)
