@@ -463,8 +463,16 @@ def main():
                          "dtype": "f32 filter + f64 exact refinement",
                          "stage_ms": {names[k]: round(float(np.mean([ev32[s_][k].elapsed_time(ev32[s_][k + 1])
                                                                        for s_ in range(args.warmup, n_steps)])), 4) for k in range(5)},
+                         "roofline": {"kernel": "crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell)",
+                                      "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "bytes_per_launch": float(np.mean(r32.crp_bytes[args.warmup:]))},
                          "scores_identical_to_f64_path": bool(torch.equal(s32[args.warmup:], last)),
                          "note": "crp_strip32_kernel + error-band check + float64 refinement (DESIGN.md section 4); same steps, same pairs"}
+    if rank == 0 and "fast32" in out:
+        rf = out["fast32"]["roofline"]
+        rf["avg_launch_ms"] = out["fast32"]["stage_ms"]["crp"]
+        rf["achieved"] = round(rf["bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
+        rf["frac"] = round(rf["achieved"] / HBM_PEAK_GBS, 4)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
