@@ -60,6 +60,16 @@ __global__ __launch_bounds__(256) void store_probe_kernel(double *__restrict__ o
             for (int r = r0; r < r1; r++)
                 if (c + 1 < cols) *reinterpret_cast<double2 *>(M + (int64_t)r * cols + c) = v;
         }
+    } else if (mode == 10) {
+        // uint32 matrix, a band of 32 rows walked right in 112-column steps (448-byte pieces, the strip kernel turned by 90 degrees)
+        uint32_t *U = reinterpret_cast<uint32_t *>(out) + (int64_t)p * rows * cols;
+        const int r0 = t * 32, r1 = min(r0 + 32, rows);
+        for (int c0 = 0; c0 < cols; c0 += 112) {
+            const int c = c0 + (tid & 63) * 2;
+            const bool on = (tid & 63) < 56 && c + 1 < cols;
+            for (int r = r0 + (tid >> 6); r < r1; r += 4)
+                if (on) *reinterpret_cast<uint2 *>(U + (int64_t)r * cols + c) = make_uint2(tid, r);
+        }
     } else if (mode == 9) {
         // float64, 112-column strips: 896-byte row pieces = 7 whole 128-byte lines when the pitch is line-aligned
         const int c = t * 112 + (tid & 63) * 2;
@@ -101,13 +111,14 @@ using namespace acoss;
 
 extern "C" int acoss_dev_store_probe(double *out, int K, int rows, int cols, int mode, void *stream)
 {
-    if (!out || K < 1 || rows < 1 || cols < 2 || (cols & 3) || mode < 0 || mode > 9) { set_error("store_probe: bad argument"); return ACOSS_EINVAL; }
+    if (!out || K < 1 || rows < 1 || cols < 2 || (cols & 3) || mode < 0 || mode > 10) { set_error("store_probe: bad argument"); return ACOSS_EINVAL; }
     int per_mat = 1;
     int64_t blocks;
     if (mode == 0) blocks = ((int64_t)K * rows * cols + 256 * 2 * 64 - 1) / (256 * 2 * 64);
     else {
         per_mat = mode == 1 ? ((rows + 127) / 128) * ((cols + 127) / 128) : (mode == 2 ? (cols + 119) / 120 : (mode == 3 ? (rows + 15) / 16 : (mode == 4 ? (rows + 63) / 64 : (mode == 5 ? (rows + 31) / 32 : (mode == 6 ? (cols + 119) / 120 : (mode == 7 ? (cols + 239) / 240 : (cols + 111) / 112))))));
         if (mode == 9) per_mat = (cols + 111) / 112;
+        if (mode == 10) per_mat = (rows + 31) / 32;
         blocks = (int64_t)K * per_mat;
     }
     if (blocks > 0x7fffffffLL) { set_error("store_probe: too large"); return ACOSS_ENOTSUP; }

@@ -15,7 +15,7 @@ cols = int(sys.argv[2]) if len(sys.argv) > 2 else 1000
 buf = torch.empty(K * rows * cols, dtype=torch.float64, device="cuda")
 nbytes = buf.numel() * 8
 st = torch.cuda.current_stream().cuda_stream
-names = {0: "linear", 1: "tiles 128x128", 2: "strips 120 cols", 3: "bands 16 rows", 4: "band64 chunk-major", 5: "band32 walk right", 6: "u32 strips 120 (480 B)", 7: "u32 strips 240 (960 B)", 8: "u32 strips 112 (448 B)", 9: "f64 strips 112 (896 B)"}
+names = {0: "linear", 1: "tiles 128x128", 2: "strips 120 cols", 3: "bands 16 rows", 4: "band64 chunk-major", 5: "band32 walk right", 6: "u32 strips 120 (480 B)", 7: "u32 strips 240 (960 B)", 8: "u32 strips 112 (448 B)", 9: "f64 strips 112 (896 B)", 10: "u32 band32 walk right 112"}
 def timed(f, reps=5):
     f(); torch.cuda.synchronize()
     ms = []
@@ -26,10 +26,10 @@ def timed(f, reps=5):
     return float(np.median(ms))
 t = timed(lambda: buf.fill_(1.0))
 print("K=%d (%.1f GB): torch fill_ %.3f ms -> %.2f TB/s" % (K, nbytes / 1e9, t, nbytes / t / 1e9))
-for mode in range(10):
+for mode in range(11):
     def f():
         rc = fn(buf.data_ptr(), K, rows, cols, mode, st)
         assert rc == 0, _lib.last_error()
     t = timed(f)
-    nb = nbytes / 2 if mode in (6, 7, 8) else nbytes
+    nb = nbytes / 2 if mode in (6, 7, 8, 10) else nbytes
     print("  mode %d %-24s %.3f ms -> %.2f TB/s" % (mode, names[mode], t, nb / t / 1e9))
