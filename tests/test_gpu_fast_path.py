@@ -414,3 +414,38 @@ def test_float32_approximate_keys_give_identical_masks(eng, golden):
                             M, N = int(batch.M[p]), int(batch.N[p])
                             want = B[int(d["crp_off"]):int(d["crp_off"]) + M * int(d["crp_pitch"])].cpu().numpy().reshape(M, -1)[:, :N]
                             assert np.array_equal(eng.unpack_mask_bits(got, batch, p), want), (ci, align, mutual, kappa, p)
+
+
+def test_float32_filter_with_useless_approximation(eng):
+    """Features with a large per-bin offset (norms ~1e6, distances ~20): the float32 approximation is worthless, its
+    error band covers whole rows (more than 64 band elements: the general refinement path), and the masks still equal the
+    float64 path's; also 13-dimensional signed features (the MFCC shape), no OTI."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(77)
+    offs = 100.0 * (np.arange(12) + 1.0)
+    lens = [210, 180, 333]
+    feats = np.concatenate([offs[None, :] + rng.standard_normal((n, 12)) for n in lens])
+    off = np.cumsum([0] + lens).astype(np.int64)
+    gc = np.stack([np.abs(rng.standard_normal(12)) for _ in lens])
+    mf = np.concatenate([np.cumsum(rng.standard_normal((n, 13)), axis=0) * 3.0 for n in lens])
+    pairs = np.array([(0, 1), (1, 2), (2, 0), (1, 1)], dtype=np.int32)
+    for F, do_oti in ((feats, True), (mf, False)):
+        corpus = eng.DeviceCorpus(F, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+        if do_oti:
+            eng.oti(corpus, batch)
+        T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+        keys = eng.crp_planar32(corpus, batch, eng.pack_x32(corpus, batch))
+        band = eng.planar32_band(corpus, batch)
+        Th, Kh, bh = T.cpu().numpy(), keys.cpu().numpy().view(np.uint32), band.cpu().numpy().astype(np.float64)
+        for p in range(batch.K):
+            d = batch.descs[p]
+            M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
+            idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+            approx = (Kh[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
+            assert np.all(np.abs(approx - Th[idx]) <= (bh[2 * p] + bh[2 * p + 1] * Th[idx]) / 2), p
+        for mutual in (True, False):
+            want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+            got, _ = eng.mask_bits_planar32(keys, band, corpus, batch, 0.095, mutual=mutual)
+            for p in range(batch.K):
+                assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (do_oti, mutual, p)
