@@ -549,7 +549,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         planar = planar_supported(corpus, batch)
         use32 = planar and (planar32_default() if approx32 is None else bool(approx32))
         # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
-        xp = pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
+        xp = None if use32 else pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
         T = _scratch("T", (batch.total_crp + 1) // 2 + 1 if planar else max(batch.total_crp, 1), torch.float64, corpus.device)
         work = _scratch("work", int(_lib.load().acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, m)), torch.uint8, corpus.device)
         B = None if planar or bits_path_supported(batch) or fused_align_supported(batch) \
