@@ -9,7 +9,7 @@
 // bit set).  Rows and columns in which another value lies within the error band of the k-th smallest are finished in
 // float64 by the fix-up kernel (planar_kernels.hip), so the masks equal those of the float64 path bit for bit.
 //
-// Error bound used by the callers: |T~ - T| <= 2^-24 * (24 * sum_k (|x_{i+k}|^2 + |y_{j+k}|^2) + 11 T) for the
+// Error bound used by the callers: |T~ - T| <= 2^-24 * (16.5 * sum_k (|x_{i+k}|^2 + |y_{j+k}|^2) + 9.5 T) for the
 // operands it is given (the host passes the corpus with its mean subtracted: same distances, a third of the norms).
 //
 // Same decomposition as the float64 kernel: a persistent 8-wave block per 120-column strip of a pair walks down in

@@ -183,8 +183,8 @@ int acoss_crp_batch_f64(const double *xp, const double *feats, const double *nor
                         double *out, void *stream);
 /* Float32 approximation of acoss_crp_planar_batch_f64's matrix (xp, feats, norms: the float64 corpus rounded to
  * float32, packed by acoss_pack_x_f32): the windowed sums computed in float32 and written as order-preserving uint32
- * keys (the float32 bit pattern with the sign bit set), same element indexing.  |approx - exact| <= 2^-24 * (24 *
- * (sum over the window of |x_{i+k}|^2 + |y_{j+k}|^2) + 11 * exact).  CRPUtils.py:67-84 + :24-45, d in {12, 13}, win == 9. */
+ * keys (the float32 bit pattern with the sign bit set), same element indexing.  |approx - exact| <= 2^-24 * (16.5 *
+ * (sum over the window of |x_{i+k}|^2 + |y_{j+k}|^2) + 9.5 * exact).  CRPUtils.py:67-84 + :24-45, d in {12, 13}, win == 9. */
 int acoss_crp_planar32_batch(const float *xp, const float *feats, const float *norms, int d,
                              const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                              uint32_t *out, void *stream);
@@ -258,7 +258,7 @@ int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, co
                                  void *work, size_t work_bytes, void *stream);
 /* acoss_mask_bits_planar_batch on the float32-approximate keys of acoss_crp_planar32_batch.  band holds two floats per
  * pair, (base, slope): twice the error bound of an approximate value v of pair p is band[2p] + band[2p+1] * v
- * (base = 2 * 24 * 2^-24 * (largest window sum of squared norms of song x + of song y), slope = 2 * 11 * 2^-24, both
+ * (base = 2 * 16.5 * 2^-24 * (largest window sum of squared norms of song x + of song y), slope = 2 * 9.5 * 2^-24, both
  * rounded up; derivation in DESIGN.md section 4).  A row / column whose k-th smallest approximate value has another
  * value within that distance is finished in float64: the values inside the band are recomputed exactly from feats /
  * norms (the float64 corpus), the rest is decided by the approximation.  The masks equal

@@ -358,7 +358,7 @@ def test_wide_forms_up_to_2048(eng, orc):
 
 
 def test_float32_approximate_keys_give_identical_masks(eng, golden):
-    """crp_planar32 (float32 windowed sums, bound 2^-24 * (24 * window norm sums + 11 * value)) + mask_bits_planar32 (error-band check,
+    """crp_planar32 (float32 windowed sums, bound 2^-24 * (16.5 * window norm sums + 9.5 * value)) + mask_bits_planar32 (error-band check,
     exact float64 refinement inside the band) == mask_bits on the float64 matrix, bit for bit: golden 1000-frame pairs,
     ragged small pairs, crafted exact ties and 1e-11 perturbations (everything inside the band), 1033 .. 2056-frame songs;
     the approximation stays inside its bound."""
@@ -449,3 +449,39 @@ def test_float32_filter_with_useless_approximation(eng):
             got, _ = eng.mask_bits_planar32(keys, band, corpus, batch, 0.095, mutual=mutual)
             for p in range(batch.K):
                 assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (do_oti, mutual, p)
+
+
+def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng):
+    """The error bound of the float32 filter assumes that v_mfma_f32_16x16x4_f32 accumulates like a chain of
+    round-to-nearest FMAs over k (as the float64 form does).  Pinned here bit for bit: the kernel's keys equal a host
+    emulation of its arithmetic in float32 (an FMA = one rounding of the exact product-sum; the product of two float32
+    is exact in float64)."""
+    from acoss_amd import synth
+    lens = iter([200, 150, 173])
+    ch = synth.make_corpus(3, 1, seed=5, lengths=lambda r: next(lens))
+    corpus = eng.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = np.array([(0, 1), (1, 2), (2, 0)], dtype=np.int32)
+    b = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    eng.oti(corpus, b)
+    keys = eng.crp_planar32(corpus, b, eng.pack_x32(corpus, b)).cpu().numpy().view(np.uint32)
+    f32, n32 = [t.cpu().numpy() for t in eng.float32_copy(corpus)]
+    shifts = b.descs_dev.cpu().numpy().view(eng.PAIR_DESC)["shift"]
+
+    def fma32(a, bb, c):
+        return (a.astype(np.float64) * bb.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    for p in range(b.K):
+        d = b.descs[p]
+        nx, ny, sh = int(d["nx"]), int(d["ny"]), int(shifts[p])
+        X = np.roll(f32[int(d["x_row0"]):int(d["x_row0"]) + nx], sh, axis=1)
+        Y = f32[int(d["y_row0"]):int(d["y_row0"]) + ny]
+        acc = np.zeros((nx, ny), dtype=np.float32)
+        for bin_ in range(12):
+            acc = fma32(X[:, bin_][:, None], Y[:, bin_][None, :], acc)
+        nsum = (n32[int(d["x_row0"]):int(d["x_row0"]) + nx][:, None] + n32[int(d["y_row0"]):int(d["y_row0"]) + ny][None, :]).astype(np.float32)
+        C = np.maximum(fma32(np.full_like(acc, -2.0), acc, nsum), np.float32(0))
+        M, N = nx - 8, ny - 8
+        T = C[0:M, 0:N].copy()
+        for k in range(1, 9):
+            T = (T + C[k:k + M, k:k + N]).astype(np.float32)
+        idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+        assert np.array_equal(keys[idx] & 0x7fffffff, T.view(np.uint32)), p
