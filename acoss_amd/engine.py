@@ -236,9 +236,23 @@ def float32_copy(corpus):
         mu = corpus.feats.mean()
         centred = corpus.feats - mu
         n64 = (centred * centred).sum(1)
+        top = float(n64.max().item()) if n64.numel() else 0.0
+        # a power-of-two scale brings the largest norm to ~1: exact in both precisions, the order of the windowed sums
+        # (all the selection looks at) does not change, and float32 neither overflows nor loses small corpora to denormals
+        corpus._f32_ok = bool(np.isfinite(top) and top > 0.0)
+        scale = 2.0 ** -round(0.5 * np.log2(top)) if corpus._f32_ok else 1.0
+        centred = centred * scale
+        n64 = n64 * (scale * scale)
+        corpus._f32_scale2 = scale * scale          # approximate values = this x the windowed sums of the original corpus
         corpus._f32 = (centred.to(torch.float32), n64.to(torch.float32))
         corpus._f32_norms64 = n64.cpu().numpy()
     return corpus._f32
+
+
+def planar32_usable(corpus):
+    """False for corpora the float32 copy cannot represent (all-zero or non-finite features): those stay on float64."""
+    float32_copy(corpus)
+    return corpus._f32_ok
 
 
 def pack_x32(corpus, batch, out=None):
@@ -548,7 +562,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         if do_oti:
             oti(corpus, batch)
         planar = planar_supported(corpus, batch)
-        use32 = planar and (planar32_default() if approx32 is None else bool(approx32))
+        use32 = planar and (planar32_default() if approx32 is None else bool(approx32)) and planar32_usable(corpus)
         # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
         xp = None if use32 else pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
         T = _scratch("T", (batch.total_crp + 1) // 2 + 1 if planar else max(batch.total_crp, 1), torch.float64, corpus.device)

@@ -397,8 +397,9 @@ def test_float32_approximate_keys_give_identical_masks(eng, golden):
                 M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
                 idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
                 approx = (Kh[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
-                bound = (bh[2 * p] + bh[2 * p + 1] * Th[idx]) / 2
-                assert np.all(Kh[idx] >> 31 == 1) and np.all(np.abs(approx - Th[idx]) <= bound), (ci, p)
+                Ts = Th[idx] * corpus._f32_scale2          # the kernel works on a power-of-two rescaled copy
+                bound = (bh[2 * p] + bh[2 * p + 1] * Ts) / 2
+                assert np.all(Kh[idx] >> 31 == 1) and np.all(np.abs(approx - Ts) <= bound), (ci, p)
             planes = eng.crp_planar(corpus, batch, eng.pack_x(corpus, batch)) if ci < 3 else None
             for mutual in (True, False):
                 for kappa in kappas:
@@ -443,7 +444,8 @@ def test_float32_filter_with_useless_approximation(eng):
             M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
             idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
             approx = (Kh[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
-            assert np.all(np.abs(approx - Th[idx]) <= (bh[2 * p] + bh[2 * p + 1] * Th[idx]) / 2), p
+            Ts = Th[idx] * corpus._f32_scale2
+            assert np.all(np.abs(approx - Ts) <= (bh[2 * p] + bh[2 * p + 1] * Ts) / 2), p
         for mutual in (True, False):
             want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
             got, _ = eng.mask_bits_planar32(keys, band, corpus, batch, 0.095, mutual=mutual)
@@ -485,3 +487,20 @@ def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng):
             T = (T + C[k:k + M, k:k + N]).astype(np.float32)
         idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
         assert np.array_equal(keys[idx] & 0x7fffffff, T.view(np.uint32)), p
+
+
+def test_float32_filter_is_scale_free(eng, orc):
+    """Corpora of very large and very small magnitude (features x 1e25, x 1e-25: squared norms beyond float32's range
+    either way): the filter works on a power-of-two rescaled copy, the scores equal the oracle's on the original data."""
+    from acoss_amd import synth
+    lens = iter([300, 220, 410])
+    ch = synth.make_corpus(3, 1, seed=19, lengths=lambda r: next(lens))
+    pairs = np.array([(0, 1), (1, 2), (2, 0)], dtype=np.int32)
+    for mag in (1e25, 1e-25):
+        feats = ch.feats * mag
+        corpus = eng.DeviceCorpus(feats, ch.frame_off, gchroma=ch.gchroma)
+        got = eng.serra09_scores(corpus, pairs, approx32=True)
+        for t, (i, j) in enumerate(pairs):
+            q, d = orc.serra09_pair(feats[ch.frame_off[i]:ch.frame_off[i + 1]], ch.gchroma[i],
+                                    feats[ch.frame_off[j]:ch.frame_off[j + 1]], ch.gchroma[j])
+            assert got["qmax"][t] == q and got["dmax"][t] == d, (mag, t)

@@ -12,8 +12,8 @@ b = engine.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
 engine.oti(corpus, b)
 keys = engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b)).cpu().numpy().view(np.uint32)
 band2 = engine.planar32_band(corpus, b).cpu().numpy().astype(np.float64).reshape(-1, 2)
-band = band2[:, 0] + band2[:, 1] * 16.5          # at a typical threshold value
-T = engine.crp(corpus, b, engine.pack_x(corpus, b)).cpu().numpy()
+band = band2[:, 0] + band2[:, 1] * 16.5 * corpus._f32_scale2          # at a typical threshold value
+T = engine.crp(corpus, b, engine.pack_x(corpus, b)).cpu().numpy() * corpus._f32_scale2
 print("band (2 x bound) per pair: min %.3g max %.3g; song wmax mean %.3g" % (band.min(), band.max(), corpus.song_wmax(9).mean()))
 for scale in (1.0, 0.25, 1 / 16.0):
     tot_r = amb_r = tot_c = amb_c = 0

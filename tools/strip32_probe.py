@@ -27,7 +27,8 @@ for align in (() if os.environ.get("ACOSS_STRIP32_NOSTORE") else (32, 1)):
         idx = (int(d["crp_off"]) + np.arange(Mm)[:, None] * int(d["crp_pitch"]) + np.arange(Nn)[None, :]).astype(np.int64)
         approx = (A[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
         assert np.all(A[idx] >> 31 == 1)
-        worst = max(worst, float(np.max(np.abs(approx - T[idx]) / (bnd[p, 0] + bnd[p, 1] * T[idx]))))
+        Ts = T[idx] * rc._f32_scale2
+        worst = max(worst, float(np.max(np.abs(approx - Ts) / (bnd[p, 0] + bnd[p, 1] * Ts))))
     print("pitch_align %d: max |approx - exact| / bound = %.4f over %d pairs" % (align, worst, b.K))
 batch = engine.PairBatch(corpus.frame_off, allp[np.arange(K) % len(allp)], 9, corpus.device, pitch_align=32)
 engine.oti(corpus, batch)
