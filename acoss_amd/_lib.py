@@ -74,6 +74,11 @@ SIGNATURES = {
     "acoss_mask_bits_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
     "acoss_mask_bits_planar_batch": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
     "acoss_mask_bits_planar32_batch": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
+    "acoss_pack_frames_f32": (_i, [_vp, _vp, _i, _i64, _vp, _vp]),
+    "acoss_mask_bits_fused_supported": (_i, [_i, _i, _i, _i]),
+    "acoss_mask_bits_fused_work_bytes": (_sz, [_i, _i, _i, _i, _i]),
+    "acoss_mask_bits_fused_batch": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _i, _vp]),
+    "acoss_mask_bits_fused_counter": (_vp, [_vp]),
     "acoss_align_bits_batch": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     "acoss_thresholds_batch": (_i, [_vp, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _sz, _vp]),
     "acoss_align_fused_batch": (_i, [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _sz, _i, _vp, _vp, _vp]),

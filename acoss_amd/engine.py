@@ -318,6 +318,68 @@ def mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=True, out=None, 
     return out, work
 
 
+def packed32(corpus):
+    """The float32 copy of a float64 corpus (float32_copy) as 16-float packed frames [d values | squared norm | 0 ...]:
+    the operand of the fused band kernel (mask_bits_fused); cached on the corpus."""
+    if getattr(corpus, "_pk32", None) is None:
+        f32, n32 = float32_copy(corpus)
+        out = torch.empty((max(corpus.n_frames, 1), 16), dtype=torch.float32, device=corpus.device)
+        check(_lib.load().acoss_pack_frames_f32(_ptr(f32), _ptr(n32), corpus.d, corpus.n_frames, _ptr(out), _stream()),
+              "pack_frames_f32")
+        corpus._pk32 = out
+    return corpus._pk32
+
+
+def fused_supported(corpus, batch):
+    """The product path: float64 chroma / MFCC-sized features, the reference's window, matrices up to 1014 x 1014."""
+    return (corpus.dtype == np.float64 and batch.K > 0
+            and bool(_lib.load().acoss_mask_bits_fused_supported(corpus.d, batch.win, batch.max_nx, batch.max_ny))
+            and planar32_usable(corpus))
+
+
+def fused_side_rows(batch):
+    """Default capacity of the side buffer of mask_bits_fused: 2 % of the batch's rows and columns (0.5-1 % ask for a slot
+    on chroma features)."""
+    rows = batch.K * (batch.max_nx + batch.max_ny - 2 * batch.win + 2)
+    return int(max(1024, 0.02 * rows))
+
+
+def mask_bits_fused(corpus, batch, kappa, mutual=True, band=None, out=None, work=None, side_rows=None, verify=True):
+    """get_csm + sliding_csm + csm_to_binary_mutual of every pair without a matrix in HBM (csrc/band_kernels.hip): returns
+    (bits, work) like mask_bits().  verify=True reads the undecided-row counter back (one synchronising 4-byte copy) and
+    repeats the call with a larger side buffer if rows were dropped; verify=False leaves that check to the caller
+    (fused_counter)."""
+    lib = _lib.load()
+    max_m = batch.max_nx - batch.win + 1
+    if band is None:
+        band = planar32_band(corpus, batch)
+    if out is None:
+        out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=corpus.device)
+    pk = packed32(corpus)
+    side_rows = int(side_rows or fused_side_rows(batch))
+    while True:
+        need = int(lib.acoss_mask_bits_fused_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win, side_rows))
+        if work is None or work.numel() < need:
+            work = torch.empty(need, dtype=torch.uint8, device=corpus.device)
+        check(lib.acoss_mask_bits_fused_batch(_ptr(pk), _ptr(band), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                              _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny,
+                                              float(kappa), int(bool(mutual)), _ptr(out), _ptr(work), work.numel(),
+                                              side_rows, _stream()), "mask_bits_fused_batch")
+        if not verify:
+            return out, work
+        asked = int(fused_counter(work).item())
+        if asked <= side_rows:
+            return out, work
+        side_rows = asked + 64          # rows were dropped: once more with room for all of them
+        work = None
+
+
+def fused_counter(work):
+    """Device int32 view of the undecided-row counter of the last mask_bits_fused call on `work`."""
+    off = int(_lib.load().acoss_mask_bits_fused_counter(_ptr(work))) - work.data_ptr()
+    return work[off:off + 4].view(torch.int32)
+
+
 def planar_elems(batch):
     """Words of the high-word matrix of a batch."""
     return max(batch.total_crp, 2)

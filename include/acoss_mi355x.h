@@ -267,6 +267,29 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
                                    int d, const acoss_pair_desc *descs, int K, int win,
                                    int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
                                    void *work, size_t work_bytes, void *stream);
+/* The product path: get_csm + sliding_csm + csm_to_binary_mutual (CRPUtils.py:67-84, :24-45, :201-219) without any
+ * matrix in HBM.  One kernel forms a 24-row band of a pair's windowed sums in float32 on the matrix cores, keeps the
+ * band's keys in registers, selects each row's k-th smallest and writes only the row's bit plane; run on (x, y) it
+ * gives the row planes, on (y, x) the column planes; acoss's mutual mask is their AND (bits: same layout as
+ * acoss_mask_bits_batch, W = 16).  Rows whose k-th smallest key has another key within the float32 error band (band:
+ * as for acoss_mask_bits_planar32_batch) are finished exactly in float64 from feats / norms, so the masks equal
+ * acoss_mask_bits_batch's on the float64 windowed sums bit for bit.
+ *   pk      packed float32 frames of the whole corpus (acoss_pack_frames_f32): 16 floats per frame, [d values |
+ *           squared norm | 0 ...], the corpus centred and scaled as the caller likes (distances only need to be
+ *           consistent with `band`); the OTI rotation of song x is applied on the fly from descs[p].shift
+ *   work    acoss_mask_bits_fused_work_bytes(K, max_nx, max_ny, win, side_rows) bytes; side_rows = capacity of the
+ *           side buffer that carries undecided rows to the refinement kernel (4 KB each; 2 % of K * (M + N) is ample).
+ *           After the stream has run, *acoss_mask_bits_fused_counter(work) (a DEVICE int) holds the number of rows that
+ *           asked for a slot: if it exceeds side_rows the masks are incomplete and the call must be repeated with at
+ *           least that many side rows.
+ * Supported: d in {12, 13}, win == 9, matrices up to 1014 x 1014 (acoss_mask_bits_fused_supported). */
+int acoss_pack_frames_f32(const float *feats, const float *norms, int d, int64_t n_frames, float *out, void *stream);
+int acoss_mask_bits_fused_supported(int d, int win, int max_nx, int max_ny);
+size_t acoss_mask_bits_fused_work_bytes(int K, int max_nx, int max_ny, int win, int side_rows);
+int acoss_mask_bits_fused_batch(const float *pk, const float *band, const double *feats, const double *norms, int d,
+                                const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
+                                int mutual, uint64_t *bits, void *work, size_t work_bytes, int side_rows, void *stream);
+const int *acoss_mask_bits_fused_counter(void *work);
 int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc *descs, int K, int win,
                            int max_nx, int max_ny, int boundary, const acoss_align_params *params,
                            float *scores, void *stream);
