@@ -243,12 +243,21 @@ __device__ inline double planar_exact_value(const double *__restrict__ feats, co
 // One row (DIR 0) or column (DIR 1) the selection kernels left unresolved, the general way: exact values for the
 // elements that share the winner's key (or, with approximate keys, lie inside its error band), then the bit-serial
 // selection over 64-bit keys.
+// Bit planes of the band kernel (band_kernels.hip) are stored shifted up by plane_shift bits: bit l of word e = position
+// 64 e + l - plane_shift.  Lane e holds natural word e; returns the shifted word e.
+__device__ inline uint64_t shifted_plane_word(uint64_t mine, int plane_shift, int lane)
+{
+    const unsigned plo = (unsigned)__shfl_up((int)(unsigned)mine, 1), phi = (unsigned)__shfl_up((int)(unsigned)(mine >> 32), 1);
+    const uint64_t prev = lane == 0 ? 0ull : (((uint64_t)phi << 32) | plo);
+    return (mine << plane_shift) | (prev >> (64 - plane_shift));
+}
+
 // key_at(q): the uint32 key of position q of the row / column (its source: the key matrix, or a compact copy of the row).
 // thr_hi: the high word the selection left for this row; thr / cut (may be null): where the final threshold goes.
 template <int DIR, int E, typename KeyAt>
 __device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
                                        const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
-                                       const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
+                                       const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     // the selection kernel left the high word the tied elements share: only those few need their exact value;
     // every other element is ordered by its high word alone
@@ -290,6 +299,7 @@ __device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const doub
             const uint64_t m = __ballot(on);
             if (lane == e) mine = m;
         }
+        if (plane_shift > 0) mine = shifted_plane_word(mine, plane_shift, lane);
         if (lane < E) bits[lane * bstride] = mine;
     }
 }
@@ -311,7 +321,7 @@ struct FixSmem {
 template <int DIR, int E, typename KeyAt>
 __device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
                                     const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
-                                    const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
+                                    const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     const unsigned th = thr_hi;
     if (th == 0u || win != 9 || d > FIX_MAXD) return false;
@@ -398,6 +408,7 @@ __device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, 
             const uint64_t m = __ballot(on);
             if (lane == e) mine = m;
         }
+        if (plane_shift > 0) mine = shifted_plane_word(mine, plane_shift, lane);
         if (lane < E) bits[lane * bstride] = mine;
     }
     __syncthreads();

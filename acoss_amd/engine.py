@@ -287,14 +287,23 @@ PLANAR32_BOUND_W = 16.5 * 2.0 ** -24
 PLANAR32_BOUND_T = 9.5 * 2.0 ** -24
 
 
-def planar32_band(corpus, batch):
-    """Per pair of the batch two float32 (base, slope): twice the error bound of a value v of crp_planar32 is
-    base + slope * v, both rounded up (device tensor of 2 K floats)."""
+def planar32_bound_w(d, fused):
+    """Coefficient of the window norm sums in the float32 error bound.  A d-step FMA chain costs (d + 2) u |x||y| on the
+    dot product, i.e. (d + 2) u N on 2 x.y (N = |x|^2 + |y|^2); the strip kernel adds 2 u N for the norms (d = 12: 16 u N,
+    DESIGN.md section 4); the fused band kernel carries the norms through the matrix product, which costs one u N more
+    (band_kernels.hip).  Half a unit of margin for second-order terms."""
+    return (d + (5.5 if fused else 4.5)) * 2.0 ** -24
+
+
+def planar32_band(corpus, batch, fused=False):
+    """Per pair of the batch two float32 (base, slope): twice the error bound of a value v of crp_planar32 (fused: of the
+    band kernel) is base + slope * v, both rounded up (device tensor of 2 K floats)."""
     w = corpus.song_wmax(batch.win)
+    bound_w = planar32_bound_w(corpus.d, fused)
     sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
     up = 1.0 + 2.0 ** -10        # covers the float32 rounding of base, slope and of base + slope * v in the kernels
     band = np.empty((batch.K, 2), dtype=np.float64)
-    band[:, 0] = 2.0 * PLANAR32_BOUND_W * (w[sx] + w[sy]) * up
+    band[:, 0] = 2.0 * bound_w * (w[sx] + w[sy]) * up
     band[:, 1] = 2.0 * PLANAR32_BOUND_T * up
     b32 = band.astype(np.float32)
     b32 = np.where(b32.astype(np.float64) < band, np.nextafter(b32, np.float32(np.inf)), b32).astype(np.float32)
@@ -352,7 +361,7 @@ def mask_bits_fused(corpus, batch, kappa, mutual=True, band=None, out=None, work
     lib = _lib.load()
     max_m = batch.max_nx - batch.win + 1
     if band is None:
-        band = planar32_band(corpus, batch)
+        band = planar32_band(corpus, batch, fused=True)
     if out is None:
         out = torch.zeros(max(batch.K * max_m * 16, 1), dtype=torch.int64, device=corpus.device)
     pk = packed32(corpus)

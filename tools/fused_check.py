@@ -67,7 +67,7 @@ def main():
     pairs = synth.all_pairs(ch.n_songs)[:P]
     batch = engine.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
     engine.oti(corpus, batch)
-    band = engine.planar32_band(corpus, batch)
+    band = engine.planar32_band(corpus, batch, fused=True)
     bits, work = engine.mask_bits_fused(corpus, batch, 0.095, band=band)
     print("undecided rows: %d of %d" % (int(engine.fused_counter(work).item()), batch.K * 2 * 992))
     for rep in range(3):

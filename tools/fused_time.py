@@ -16,7 +16,7 @@ corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
 pairs = synth.all_pairs(ch.n_songs)[:P]
 batch = engine.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
 engine.oti(corpus, batch)
-band = engine.planar32_band(corpus, batch)
+band = engine.planar32_band(corpus, batch, fused=True)
 bits, work = engine.mask_bits_fused(corpus, batch, 0.095, band=band)
 ms = []
 for rep in range(reps):
