@@ -16,12 +16,63 @@
 namespace acoss {
 
 
+// ---- side buffer: undecided rows / columns of the float32-approximate selection ------------------------------
+// The wave that could not decide a row holds its keys in registers in position order: it writes them to a slot (4 KB,
+// coalesced) and the refinement kernel below finishes the row from there -- no second strided walk over the key matrix
+// (the column refinement of select_fix_planar_kernel reads 3.3 GB per 4096 pairs that way).
+constexpr int SELECT_HANDED_OVER = -3;
+
+template <int E>
+__device__ inline void side_hand_over(const unsigned (&h)[E], const ThreshWork &w, int p, int dir, int which, int len,
+                                      SelectResult &res, int lane)
+{
+    if (w.side_keys == nullptr) return;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(w.side_counter, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= w.side_cap) return;            // no room: stays unresolved for the strided fix-up kernel
+    uint32_t *dst = w.side_keys + (int64_t)slot * 1024;
+#pragma unroll
+    for (int e = 0; e < E; e++)
+        if (e * 64 + lane < len) dst[e * 64 + lane] = h[e];
+    if (lane == 0) w.side_slots[slot] = make_int4(p, dir, which, (int)(unsigned)(res.thr_key >> 32));
+    res.cut = SELECT_HANDED_OVER;
+}
+
+__global__ __launch_bounds__(64) void select_fix_side_kernel(const double *__restrict__ feats, const double *__restrict__ norms, int d,
+                                                             const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
+                                                             ThreshWork w)
+{
+    __shared__ FixSmem sm;
+    const int slot = blockIdx.x;
+    if (slot >= min(*w.side_counter, w.side_cap)) return;
+    const int4 rec = w.side_slots[slot];
+    const int p = rec.x, dir = rec.y, which = rec.z;
+    const unsigned thr_hi = (unsigned)rec.w;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int len = dir ? M : N;
+    const int lane = threadIdx.x;
+    const int k = knn_count(k_mode, kv, len);
+    const uint32_t *keys = w.side_keys + (int64_t)slot * 1024;
+    auto key_at = [&](int q) { return keys[q]; };
+    uint64_t *thr = dir ? w.col_thr + (int64_t)p * w.max_n : w.row_thr + (int64_t)p * w.max_m;
+    int *cut = dir ? w.col_cut + (int64_t)p * w.max_n : w.row_cut + (int64_t)p * w.max_m;
+    if (dir == 0) {
+        if (fix_row_band<0, 16>(sm, key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) return;
+        fix_row_generic<0, 16>(key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+    } else {
+        if (fix_row_band<1, 16>(sm, key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) return;
+        fix_row_generic<1, 16>(key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+    }
+}
+
 // ---- rows ------------------------------------------------------------------------------------------------
 constexpr int PL_ROWS_PER_WAVE = 8;
 
 // MODE (development probes): 1 = loads only
 template <int MODE = 0, int E = 16>
-__global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kernel(const uint32_t *__restrict__ Thi,
+__global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kernel(const uint32_t *__restrict__ Thi,
                                                                    const acoss_pair_desc *__restrict__ descs, int win,
                                                                    double kv, int k_mode, ThreshWork w, int rows_blocks)
 {
@@ -41,7 +92,7 @@ __global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kerne
     unsigned *hist = hist_all + wave * HIST_WORDS;
     hist_clear(hist, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
-    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
+    HistWarm warm{0, (E == 16 ? HIST256_SHIFT0 : HIST_WARM_SHIFT0) + (w.band != nullptr ? 3 : 0)};
     const uint64_t valid = planar_slot_valid<E>(N, lane);
     const bool wide = N > (E - 1) * 64;       // wave-uniform: only the last slot can run past the row
     for (int i = r0; i < r1; i++) {
@@ -70,14 +121,18 @@ __global__ __launch_bounds__(256, E == 16 ? 6 : 4) void select_rows_planar_kerne
         }
         SelectResult res;
         if (!planar_trivial(k, N, res)) {
-            res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
+            if constexpr (E == 16) res = wave_select_hist256_u32(h, N, k, hist, lane, warm);
+            else res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
             band_resolve<E>(h, N, w.band, p, lane, res);
+        }
+        if constexpr (E == 16) {
+            if (w.band != nullptr && res.cut == SELECT_UNRESOLVED) side_hand_over<E>(h, w, p, 0, i, N, res, lane);
         }
         if (lane == 0) {
             thr[i] = res.thr_key;
             cut[i] = res.cut;
         }
-        if (w.row_bits && res.cut != SELECT_UNRESOLVED)
+        if (w.row_bits && res.cut != SELECT_UNRESOLVED && res.cut != SELECT_HANDED_OVER)
             planar_emit_bits<E>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
                                 w.row_bits + ((int64_t)p * w.max_m + i) * E, lane);
     }
@@ -166,19 +221,20 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<16>(M, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
-    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
+    HistWarm warm{0, HIST256_SHIFT0 + (w.band != nullptr ? 3 : 0)};
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
         else if (!planar_trivial(k, M, res)) {
-            res = wave_select_hist_u32<16>(h, M, k, hist, lane, warm);
+            res = wave_select_hist256_u32(h, M, k, hist, lane, warm);
             band_resolve<16>(h, M, w.band, p, lane, res);
         }
+        if (w.band != nullptr && res.cut == SELECT_UNRESOLVED) side_hand_over<16>(h, w, p, 1, j, M, res, lane);
         if (lane == 0) {
             w.col_thr[(int64_t)p * w.max_n + j] = res.thr_key;
             w.col_cut[(int64_t)p * w.max_n + j] = res.cut;
         }
-        if (w.col_bits && res.cut != SELECT_UNRESOLVED)
+        if (w.col_bits && res.cut != SELECT_UNRESOLVED && res.cut != SELECT_HANDED_OVER)
             planar_emit_bits<16>(h, res.cut < 0 ? 0u : (unsigned)(res.thr_key >> 32), res.cut < 0 ? 0ull : valid,
                                  w.col_word(p, j, 0), lane, w.max_n);
     };
@@ -265,30 +321,34 @@ template <int DIR, int E = 16>
 __global__ __launch_bounds__(64) void select_fix_planar_kernel(const uint32_t *__restrict__ Thi, const double *__restrict__ feats,
                                                                const double *__restrict__ norms, int d,
                                                                const acoss_pair_desc *__restrict__ descs, int win,
-                                                               double kv, int k_mode, ThreshWork w, int groups)
+                                                               double kv, int k_mode, ThreshWork w, int groups, int64_t total)
 {
     __shared__ FixSmem sm;
-    const int p = blockIdx.x / groups, g = blockIdx.x % groups;
-    const acoss_pair_desc ds = descs[p];
-    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    const int count = DIR == 0 ? M : N;
-    const int len = DIR == 0 ? N : M;
     const int lane = threadIdx.x;
-    const int t = g * 64 + lane;
-    uint64_t *thr = (DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n);
-    int *cut = (DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n);
-    unsigned long long todo = __ballot(t < count && cut[t] == SELECT_UNRESOLVED);
-    if (todo == 0) return;
-    const int k = knn_count(k_mode, kv, len);
-    while (todo) {
-        const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
-        todo &= todo - 1;
-        auto key_at = [&](int q) {
-            return Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
-        };
-        const unsigned thr_hi = (unsigned)(thr[which] >> 32);
-        if (w.band != nullptr && fix_row_band<DIR, E>(sm, key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) continue;
-        fix_row_generic<DIR, E>(key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+    // behind the side-buffer refinement this kernel only takes what did not fit there: nothing, as a rule
+    if (w.side_counter != nullptr && *w.side_counter <= w.side_cap) return;
+    for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+        const int p = (int)(blk / groups), g = (int)(blk % groups);
+        const acoss_pair_desc ds = descs[p];
+        const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+        const int count = DIR == 0 ? M : N;
+        const int len = DIR == 0 ? N : M;
+        const int t = g * 64 + lane;
+        uint64_t *thr = (DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n);
+        int *cut = (DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n);
+        unsigned long long todo = __ballot(t < count && cut[t] == SELECT_UNRESOLVED);
+        if (todo == 0) continue;
+        const int k = knn_count(k_mode, kv, len);
+        while (todo) {
+            const int which = g * 64 + (__ffsll((long long)todo) - 1);     // wave-uniform
+            todo &= todo - 1;
+            auto key_at = [&](int q) {
+                return Thi[planar_word(ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which))];
+            };
+            const unsigned thr_hi = (unsigned)(thr[which] >> 32);
+            if (w.band != nullptr && fix_row_band<DIR, E>(sm, key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) continue;
+            fix_row_generic<DIR, E>(key_at, thr_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+        }
     }
 }
 
@@ -322,7 +382,14 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
     }
     ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
     w.band = band;
+    if (band == nullptr || probe != 0 || getenv("ACOSS_NO_SIDE_FIX")) {       // exact keys: nothing is handed over
+        w.side_counter = nullptr;
+        w.side_slots = nullptr;
+        w.side_keys = nullptr;
+        w.side_cap = 0;
+    }
     if (K == 0) return ACOSS_OK;
+    if (w.side_counter) ACOSS_HIP(hipMemsetAsync(w.side_counter, 0, 256, st));
     double kv;
     int mode;
     kappa_mode_planar(kappa, kv, mode);
@@ -337,7 +404,7 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         int rc = launch_check("select_rows_planar_kernel<32>");
         if (rc) return rc;
         const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
-        hipLaunchKernelGGL((select_fix_planar_kernel<0, 32>), dim3((unsigned)((int64_t)K * gm)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gm);
+        hipLaunchKernelGGL((select_fix_planar_kernel<0, 32>), dim3((unsigned)((int64_t)K * gm)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gm, (int64_t)K * gm);
         rc = launch_check("select_fix_planar_kernel<rows, 32>");
         if (rc) return rc;
         if (mutual) {
@@ -348,7 +415,7 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
             hipLaunchKernelGGL(select_cols_planar_wide_kernel<WC>, dim3((unsigned)((int64_t)K * cbw)), dim3(64 * WC), ldw, st, planes, descs, win, kv, mode, w, cbw);
             rc = launch_check("select_cols_planar_wide_kernel");
             if (rc) return rc;
-            hipLaunchKernelGGL((select_fix_planar_kernel<1, 32>), dim3((unsigned)((int64_t)K * gn)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gn);
+            hipLaunchKernelGGL((select_fix_planar_kernel<1, 32>), dim3((unsigned)((int64_t)K * gn)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gn, (int64_t)K * gn);
             rc = launch_check("select_fix_planar_kernel<cols, 32>");
             if (rc) return rc;
         }
@@ -373,10 +440,12 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         int rc = launch_check("select_rows_planar_kernel");
         if (rc) return rc;
         if (probe == 2) return ACOSS_OK;
-        const int groups = ceil_div(max_m, 64);
-        hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups);
-        rc = launch_check("select_fix_planar_kernel<rows>");
-        if (rc) return rc;
+        if (!w.side_keys) {
+            const int groups = ceil_div(max_m, 64);
+            hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups, (int64_t)K * groups);
+            rc = launch_check("select_fix_planar_kernel<rows>");
+            if (rc) return rc;
+        }
     }
     if (mutual || probe == 12) {
         ACOSS_HIP(hipFuncSetAttribute((const void *)select_cols_planar_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -384,9 +453,23 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         int rc = launch_check("select_cols_planar_kernel");
         if (rc) return rc;
         if (probe == 12) return ACOSS_OK;
-        const int groups = ceil_div(max_n, 64);
-        hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups);
-        rc = launch_check("select_fix_planar_kernel<cols>");
+        if (!w.side_keys) {
+            const int groups = ceil_div(max_n, 64);
+            hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3((unsigned)((int64_t)K * groups)), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, groups, (int64_t)K * groups);
+            rc = launch_check("select_fix_planar_kernel<cols>");
+            if (rc) return rc;
+        }
+    }
+    if (w.side_keys) {
+        // undecided rows and columns: one wave per side-buffer slot; what did not fit (never, with a 2 % buffer, on real
+        // features) is still marked unresolved and goes the strided way
+        hipLaunchKernelGGL(select_fix_side_kernel, dim3((unsigned)w.side_cap), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w);
+        int rc = launch_check("select_fix_side_kernel");
+        if (rc) return rc;
+        const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
+        hipLaunchKernelGGL(select_fix_planar_kernel<0>, dim3(2048), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gm, (int64_t)K * gm);
+        if (mutual) hipLaunchKernelGGL(select_fix_planar_kernel<1>, dim3(2048), dim3(64), 0, st, planes, feats, norms, d, descs, win, kv, mode, w, gn, (int64_t)K * gn);
+        rc = launch_check("select_fix_planar_kernel (overflow)");
         if (rc) return rc;
     }
     return launch_combine_bits(descs, K, win, mutual, w, bits, st);

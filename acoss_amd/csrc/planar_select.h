@@ -164,6 +164,135 @@ __device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int 
     return res;
 }
 
+// The same selection with a single-level histogram of 256 bins per wave (16 keys per lane): lane l owns bins 4l .. 4l+3,
+// so the counters are read and cleared with ONE conflict-free 16-byte access per lane -- wave_select_hist_u32 reads
+// 4 x 16 bytes at a 64-byte lane stride (4-way bank conflicts on the reads and on the clears) and needs a second, dependent
+// LDS read for its second level.  Bins are 4x wider for the same window; the 1-3 keys of the winning bin are ranked by
+// v_readlane as before.  hist: 256 + 64 words, zero on entry and on return.  warm.shift is in this function's own bins
+// (HIST256_SHIFT0 for float64 high words, + 3 for float32 keys).
+constexpr int HIST256_LOG2 = 8, HIST256_BINS = 1 << HIST256_LOG2;
+constexpr int HIST256_SHIFT0 = HIST_WARM_SHIFT0 + 2, HIST256_SHIFT_MAX = HIST_WARM_SHIFT_MAX + 5;
+
+__device__ inline void hist256_clear(unsigned *hist, int lane)
+{
+    reinterpret_cast<uint4 *>(hist)[lane] = make_uint4(0, 0, 0, 0);
+    hist[HIST256_BINS + lane] = 0;
+}
+
+__device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], int n, int k, unsigned *hist, int lane, HistWarm &warm)
+{
+    constexpr int E = 16;
+    SelectResult res;
+    res.thr_key = 0;
+    res.cut = SELECT_UNRESOLVED;
+    unsigned bin[E];
+    enum { PREDICTED, FULL, REFINE };
+    int kind = warm.hi != 0 ? PREDICTED : FULL;
+    unsigned lo = 0;
+    int shift = warm.shift;
+    if (kind == PREDICTED) {
+        const unsigned half = (unsigned)(HIST256_BINS / 2) << shift;
+        lo = max(warm.hi, half) - half;
+    }
+    int r = 0, cstar = 0;
+    unsigned ch = 0;
+    uint64_t any = 0;
+    for (;;) {
+        int below = 0;
+        if (kind == FULL) {
+            unsigned mn = 0xffffffffu, mx = 0u;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                mn = min(mn, h[e]);
+                mx = max(mx, h[e]);
+            }
+            mn = wave_umin(mn);
+            mx = wave_umax(mx);
+            lo = mn;
+            shift = max(0, 32 - (int)__clz(mx - mn) - HIST256_LOG2);
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) below += __popcll(__ballot((h[e] < lo) & (e * 64 + lane < n)));
+        }
+        const unsigned spill = (unsigned)(HIST256_BINS + lane);
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            unsigned b = min((h[e] - lo) >> shift, spill);
+            asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
+            b = e * 64 + lane < n ? b : spill;
+            bin[e] = b;
+            atomicAdd(&hist[b], 1u);
+        }
+        const int kk = k - below;
+        const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[lane];
+        const int tot = (int)(c4.x + c4.y + c4.z + c4.w);
+        const int incl = wave_scan<OpAdd>(tot, 0);
+        hist256_clear(hist, lane);
+        const uint64_t m1 = __ballot((incl - tot < kk) & (kk <= incl));
+        if (m1 == 0) {
+            if (kind != PREDICTED) return res;
+            warm.shift = min(warm.shift + 1, HIST256_SHIFT_MAX);
+            kind = FULL;
+            continue;
+        }
+        const int ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
+        r = kk - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
+        const int c0 = __builtin_amdgcn_readlane((int)c4.x, ls), c1 = __builtin_amdgcn_readlane((int)c4.y, ls);
+        const int c2 = __builtin_amdgcn_readlane((int)c4.z, ls), c3 = __builtin_amdgcn_readlane((int)c4.w, ls);
+        int ts = 0;
+        cstar = c0;
+        if (r > c0) {
+            r -= c0; ts = 1; cstar = c1;
+            if (r > c1) {
+                r -= c1; ts = 2; cstar = c2;
+                if (r > c2) { r -= c2; ts = 3; cstar = c3; }
+            }
+        }
+        const unsigned bstar = (unsigned)(4 * ls + ts);
+        uint64_t dup = 0;
+        any = 0;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const bool in = bin[e] == bstar;
+            const uint64_t m = __ballot(in);
+            dup |= any & m;
+            any |= m;
+            ch = in ? h[e] : ch;
+        }
+        if (dup == 0) break;
+        if (shift == 0) {                   // equal high words in one lane: exact values needed, fix-up pass
+            res.thr_key = (uint64_t)(lo + bstar) << 32;       // (tells it which high word the ties share)
+            return res;
+        }
+        lo += bstar << shift;
+        shift = max(shift - HIST256_LOG2, 0);
+        kind = REFINE;
+    }
+    const bool mine = (any >> lane) & 1;
+    int less = 0, equal = 1;
+    if (cstar > 1) {
+        equal = 0;
+        for (uint64_t rest = any; rest != 0; rest &= rest - 1) {
+            const int c = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)rest) - 1);
+            const unsigned vc = (unsigned)__builtin_amdgcn_readlane((int)ch, c);
+            less += vc < ch;
+            equal += vc == ch;
+        }
+    }
+    const uint64_t win = __ballot(mine & (less < r) & (r <= less + equal));
+    if (win == 0) return res;
+    const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)win) - 1);
+    const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)ch, wl);
+    if (__builtin_amdgcn_readlane(equal, wl) > 1) {                 // shared high word: exact values decide, fix-up pass
+        res.thr_key = (uint64_t)th << 32;
+        return res;
+    }
+    res.thr_key = ((uint64_t)th << 32) | 0xffffffffull;
+    res.cut = 0x7fffffff;
+    warm.hi = th;
+    return res;
+}
+
 // ---- float32-approximate keys: the error band around a threshold ----------------------------------------------
 // Keys are float32 bit patterns (values >= +0) with the sign bit set.  [lo, hi] = the keys of the values within `band`
 // of the value of key th, widened by one ulp each way for the rounding of the two float operations.

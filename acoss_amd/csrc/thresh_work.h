@@ -24,16 +24,34 @@ struct ThreshWork {
     // approximate value v is base + slope * v; a row or column is resolved only if no other key lies within that distance
     // of its k-th smallest.  nullptr: exact high words.
     const float *band;
+    // optional (float32-approximate keys): rows / columns the selection kernels could not decide hand their keys (position
+    // order, 4 KB each) to the refinement kernel through these slots; side_counter[0] = slots asked for (beyond side_cap
+    // the row stays marked unresolved in row_cut / col_cut and the strided fix-up kernels pick it up)
+    int *side_counter;
+    int4 *side_slots;       // {pair, direction, index, high word the selection left}
+    uint32_t *side_keys;    // [side_cap][1024]
+    int side_cap;
     __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };
 
 // uint64 words per row of the bit planes and of the bit-packed mask: 16 up to 1024 x 1024, 32 up to 2048 x 2048
 inline int mask_bits_words(int max_m, int max_n) { return (max_m > 1024 || max_n > 1024) ? 32 : 16; }
 
+// capacity of the side buffer that travels with the bit planes: 2 % of the rows and columns (0.5 - 1 % ask for a slot)
+inline int thresh_side_cap(int K, int max_m, int max_n)
+{
+    const double rows = (double)K * (double)(max_m + max_n);
+    const double cap = rows * 0.02 < 1024.0 ? 1024.0 : rows * 0.02;
+    return cap > 4.0e6 ? 4000000 : (int)cap;
+}
+
 inline size_t thresh_work_bytes(int K, int max_m, int max_n, bool with_bits)
 {
     size_t b = (size_t)K * (size_t)(max_m + max_n) * (sizeof(uint64_t) + sizeof(int)) + 64;
-    if (with_bits) b += (size_t)K * (size_t)(max_m + max_n) * mask_bits_words(max_m, max_n) * sizeof(uint64_t) + 64;
+    if (with_bits) {
+        b += (size_t)K * (size_t)(max_m + max_n) * mask_bits_words(max_m, max_n) * sizeof(uint64_t) + 64;
+        if (mask_bits_words(max_m, max_n) == 16) b += 512 + (size_t)thresh_side_cap(K, max_m, max_n) * (sizeof(int4) + 1024 * sizeof(uint32_t));
+    }
     return b;
 }
 
@@ -49,12 +67,24 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
     w.row_bits = nullptr;
     w.col_bits = nullptr;
     w.band = nullptr;
+    w.side_counter = nullptr;
+    w.side_slots = nullptr;
+    w.side_keys = nullptr;
+    w.side_cap = 0;
     w.wpr = mask_bits_words(max_m, max_n);
     if (with_bits) {
         uintptr_t a = (uintptr_t)(w.col_cut + (size_t)K * max_n);
         a = (a + 63) & ~(uintptr_t)63;
         w.row_bits = (uint64_t *)a;
         w.col_bits = w.row_bits + (size_t)K * max_m * w.wpr;
+        if (w.wpr == 16) {
+            a = (uintptr_t)(w.col_bits + (size_t)K * max_n * w.wpr);
+            a = (a + 255) & ~(uintptr_t)255;
+            w.side_counter = (int *)a;
+            w.side_cap = thresh_side_cap(K, max_m, max_n);
+            w.side_slots = (int4 *)(a + 256);
+            w.side_keys = (uint32_t *)(a + 256 + (size_t)w.side_cap * sizeof(int4));
+        }
     }
     return w;
 }
