@@ -79,12 +79,17 @@ class CoverAlgorithm(object):
         self.similarity_types = similarity_types
         self.cache2dir = None
         if do_memmaps:
-            if not os.path.isdir(cachedir):
-                os.makedirs(cachedir)
+            os.makedirs(cachedir, exist_ok=True)
             self.Ds = {}
+            # one process per GPU (torch.distributed): the file-backed matrices belong to rank 0, the other ranks keep
+            # theirs in memory (every rank opening the same file with 'w+' would truncate it under the others)
+            owner = int(os.environ.get("RANK", "0")) == 0
             for s in similarity_types:
-                self.Ds[s] = np.memmap('%s_%s_dmat' % (self.get_cacheprefix(), s), shape=(self.N, self.N),
-                                       mode='w+', dtype='float32')
+                if owner:
+                    self.Ds[s] = np.memmap('%s_%s_dmat' % (self.get_cacheprefix(), s), shape=(self.N, self.N),
+                                           mode='w+', dtype='float32')
+                else:
+                    self.Ds[s] = np.zeros((self.N, self.N), dtype=np.float32)
         print("Initialized %s algorithm on %i songs in dataset %s" % (name, self.N, shortname))
 
     def set_cache2dir(self, cache2dir):
@@ -179,7 +184,8 @@ class CoverAlgorithm(object):
             mine = np.arange(len(all_pairs))
             if world > 1:
                 from . import sharding
-                mine = sharding.shard_indices(self._pair_costs(all_pairs), world, rank)
+                costs = self._pair_costs(all_pairs)
+                mine = sharding.shard_indices(costs, world, rank)
             local = {s: np.zeros(len(mine)) for s in self.similarity_types}
             memmaps, self.do_memmaps = self.do_memmaps, False     # scatter once at the end instead
             try:
@@ -197,7 +203,8 @@ class CoverAlgorithm(object):
                     import torch
                     from . import sharding
                     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-                    full = sharding.gather_scores(torch.from_numpy(local[s]).to(dev), mine, len(all_pairs)).cpu().numpy()
+                    full = sharding.gather_scores(torch.from_numpy(local[s]).to(dev), mine, len(all_pairs),
+                                                  index_of_rank=lambda r: sharding.shard_indices(costs, world, r)).cpu().numpy()
                 self.Ds[s][all_pairs[:, 0], all_pairs[:, 1]] = full
             self.get_all_clique_ids()
             if symmetric:

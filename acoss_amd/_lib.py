@@ -91,6 +91,11 @@ SIGNATURES = {
     "acoss_snf_scratch_bytes": (_sz, [_vp, _vp, _i, _i]),
     "acoss_snf_cross_batch": (_i, [_vp, _i, _i, _vp, _vp, _dbl, _dbl, _i, _vp, _sz, _vp, _vp, _vp, _vp, _vp]),
     "acoss_eval_ranks": (_i, [_vp, _i, _i64, _vp, _vp, _i, _vp, _vp]),
+    "acoss_corpus_create": (_i, [_vp, _vp, _i, _i, _vp, _i, ctypes.POINTER(_vp)]),
+    "acoss_corpus_wrap": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _i, _i, ctypes.POINTER(_vp)]),
+    "acoss_corpus_destroy": (None, [_vp]),
+    "acoss_serra09_scratch_bytes": (_sz, [_vp, _vp, _i, _i, _i]),
+    "acoss_serra09_scores": (_i, [_vp, _vp, _i, _i, _dbl, _i, _i, _i, _vp, _sz, _vp, _vp, _vp, _vp]),
     "acoss_swc_batch": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp]),
 }
 

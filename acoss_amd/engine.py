@@ -66,6 +66,13 @@ class DeviceCorpus(object):
     def lengths(self):
         return np.diff(self.frame_off)
 
+    def __del__(self):
+        for h in getattr(self, "_chandles", []):
+            try:
+                _lib.load().acoss_corpus_destroy(h)
+            except Exception:
+                pass
+
     def song_wmax(self, win):
         """Per song, the largest sum of squared (centred: float32_copy) frame norms over `win` consecutive frames (host
         float64): the scale of the error bound of the float32-approximate windowed sums (crp_planar32)."""
@@ -601,13 +608,68 @@ def fused_default():
     return os.environ.get("ACOSS_FUSED", "0") not in ("0", "", "false", "no")
 
 
+def _c_corpus(corpus, with32):
+    """The C-side handle of a float64 corpus (acoss_corpus_wrap around this object's device arrays): what
+    acoss_serra09_scores takes.  with32: hand over the centred float32 copy too (float32 filter on)."""
+    attr = "_chandle32" if with32 else "_chandle64"
+    h = getattr(corpus, attr, None)
+    if h is None:
+        lib = _lib.load()
+        f32 = n32 = ns = None
+        if with32:
+            f32, n32 = float32_copy(corpus)
+            ns = np.ascontiguousarray(corpus._f32_norms64, dtype=np.float64)
+        h = ctypes.c_void_p()
+        nb = int(corpus.gchroma.shape[1]) if corpus.gchroma is not None else 0
+        check(lib.acoss_corpus_wrap(_ptr(corpus.feats), _ptr(corpus.norms), _ptr(corpus.gchroma), nb, _ptr(f32), _ptr(n32),
+                                    ns.ctypes.data if ns is not None else None, corpus.frame_off.ctypes.data,
+                                    corpus.n_songs, corpus.d, ctypes.byref(h)), "corpus_wrap")
+        setattr(corpus, attr, h)
+        corpus._chandles = getattr(corpus, "_chandles", []) + [h]
+    return h
+
+
 def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None, approx32=None):
     """
-    Serra09.py:166-175 for every pair, fast path: oti -> pack_x -> crp (fused CSM + sliding window,
-    squared) -> mutual binarise -> qmax [-> dmax on qmax's boundary].  Falls back to the staged
-    chain for shapes the fused kernel does not cover.  Scores are divided by (M+N).
-    want may also hold "swc": swalignimpconstrained on the same mutual mask (BASELINE config 3; the
-    reference's plugins call it as `swconstrained(B, D, M, N) / (M + N)`, EarlySNF_Old.py:199-203).
+    Serra09.py:166-175 for every pair: OTI -> cross-similarity + sliding window -> mutual kNN mask -> qmax [-> dmax on the
+    D qmax leaves behind] [-> swalignimpconstrained, BASELINE config 3: the reference's plugins call it as
+    `swconstrained(B, D, M, N) / (M + N)`, EarlySNF_Old.py:199-203].  Scores are divided by (M + N).
+
+    float64 corpora go through the library's own scorer (acoss_serra09_scores, csrc/scorer.hip: batch planning, size
+    classes, the float32 filter, one synchronisation at the end); this function only hands over the pair list and a
+    scratch buffer.  approx32=False (or ACOSS_PLANAR32=0) keeps the windowed sums in float64.
+    """
+    bad = [k for k in want if k not in ("qmax", "dmax", "swc")]
+    if bad:
+        raise AcossError("serra09_scores: unknown score(s) %r (qmax, dmax, swc)" % (bad,))
+    if corpus.dtype == np.float64 and not fused_default():
+        lib = _lib.load()
+        pairs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1, 2)
+        K = pairs.shape[0]
+        out = {k: np.zeros(K) for k in want}
+        if K == 0:
+            return out
+        use32 = (planar32_default() if approx32 is None else bool(approx32)) and planar32_usable(corpus)
+        h = _c_corpus(corpus, use32)
+        bp = int(batch_pairs) if batch_pairs else 0
+        need = int(lib.acoss_serra09_scratch_bytes(h, pairs.ctypes.data, K, int(m), bp))
+        if need == 0:
+            raise AcossError("serra09_scores: %s" % _lib.last_error())
+        scratch = _scratch("scorer", need, torch.uint8, corpus.device)
+        mask = sum(b for k, b in (("qmax", 1), ("dmax", 2), ("swc", 4)) if k in want)
+        ptr = lambda k: out[k].ctypes.data if k in out else None
+        check(lib.acoss_serra09_scores(h, pairs.ctypes.data, K, int(m), float(kappa), int(bool(do_oti)), mask, bp,
+                                       _ptr(scratch), scratch.numel(), ptr("qmax"), ptr("dmax"), ptr("swc"), _stream()),
+              "serra09_scores")
+        return out
+    return serra09_scores_py(corpus, pairs, m, kappa, do_oti, want, batch_pairs, approx32)
+
+
+def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "dmax"), batch_pairs=None, approx32=None):
+    """
+    The same chain composed in Python from the stage entry points (float32 corpora; ACOSS_FUSED=1: masks from the fused
+    band kernel; and the tests that compare the two compositions).  Falls back to the staged chain for shapes the fused
+    kernels do not cover.
     """
     if not crp_supported(corpus, m):
         return serra09_scores_staged(corpus, pairs, m, kappa, do_oti, want, batch_pairs)
@@ -625,7 +687,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
     if cls.min() != cls.max():
         for c in np.unique(cls):
             part = np.flatnonzero(cls == c)
-            res = serra09_scores(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs, approx32)
+            res = serra09_scores_py(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs, approx32)
             for k in want:
                 out[k][part] = res[k]
         return out
@@ -641,6 +703,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
             oti(corpus, batch)
         planar = planar_supported(corpus, batch)
         use32 = planar and (planar32_default() if approx32 is None else bool(approx32)) and planar32_usable(corpus)
+        fused = use32 and fused_default() and fused_supported(corpus, batch)
         # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
         xp = None if use32 else pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))
         T = _scratch("T", (batch.total_crp + 1) // 2 + 1 if planar else max(batch.total_crp, 1), torch.float64, corpus.device)
@@ -660,7 +723,9 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
                 if kind in want:
                     out[kind][lo:lo + len(sel)] = align(kind, B, mats, **kw).cpu().numpy().astype(np.float64) / denom
             continue
-        if use32:
+        if fused:
+            bits, _ = mask_bits_fused(corpus, batch, kappa, mutual=True, out=bits_buf)
+        elif use32:
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
             keys = crp_planar32(corpus, batch, xp32, out=T.view(torch.int32)[:planar_elems(batch)])
             bits, work = mask_bits_planar32(keys, planar32_band(corpus, batch), corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
@@ -731,6 +796,8 @@ def serra09_scores_staged(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("q
             out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats).cpu().numpy().astype(np.float64) / denom
         if "dmax" in want:
             out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
+        if "swc" in want:
+            out["swc"][lo:lo + len(sel)] = align("swc", B, mats).cpu().numpy().astype(np.float64) / denom
         if keep is not None:
             keep.update(batch=batch, C=C, S=S, B=B)
     return out

@@ -34,11 +34,14 @@ def shard_indices(costs, world_size, rank):
     return np.sort(order[owner == rank])
 
 
-def gather_scores(local_scores, local_idx, K, group=None):
+def gather_scores(local_scores, local_idx, K, group=None, index_of_rank=None):
     """
-    All-gather of per-rank score vectors into the full length-K vector (on every rank).
+    All-gather of per-rank score vectors into the full length-K vector (on every rank): the path's ONE collective.
     local_scores: float tensor (n_local,) on this rank's device (GPU for nccl, CPU for gloo);
     local_idx: the int64 positions of those scores in the global pair list.
+    index_of_rank: callable rank -> positions owned by that rank.  The shards of shard_indices() are a deterministic
+    function of (costs, world_size, rank), so every rank can name every other rank's positions and only the scores
+    travel; without it the positions ride along (as int64 bit patterns in a second half of the message).
     Shards are padded to a common length so that one all_gather_into_tensor moves everything.
     """
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
@@ -48,18 +51,29 @@ def gather_scores(local_scores, local_idx, K, group=None):
     world = dist.get_world_size(group)
     dev = local_scores.device
     n_max = -(-K // world)
-    send = torch.zeros(2 * n_max, dtype=torch.float64, device=dev)
     n = local_scores.numel()
+    out = torch.zeros(K, dtype=local_scores.dtype, device=dev)
+    if index_of_rank is not None:
+        send = torch.zeros(n_max, dtype=local_scores.dtype, device=dev)
+        send[:n] = local_scores
+        recv = torch.empty(world * n_max, dtype=local_scores.dtype, device=dev)
+        dist.all_gather_into_tensor(recv, send, group=group)
+        recv = recv.view(world, n_max)
+        for r in range(world):
+            idx = torch.as_tensor(np.asarray(index_of_rank(r)), device=dev, dtype=torch.long)
+            out[idx] = recv[r, :idx.numel()]
+        return out
+    send = torch.zeros(2 * n_max, dtype=torch.float64, device=dev)
     send[:n] = local_scores.to(torch.float64)
-    send[n_max:n_max + n] = torch.as_tensor(local_idx, device=dev, dtype=torch.float64)
-    send[n_max + n:] = -1.0
+    idx_part = send[n_max:].view(torch.int64)
+    idx_part[:n] = torch.as_tensor(local_idx, device=dev, dtype=torch.int64)
+    idx_part[n:] = -1
     recv = torch.empty(world * 2 * n_max, dtype=torch.float64, device=dev)
     dist.all_gather_into_tensor(recv, send, group=group)
     recv = recv.view(world, 2, n_max)
-    idx = recv[:, 1, :].reshape(-1).to(torch.long)
+    idx = recv[:, 1, :].reshape(-1).view(torch.int64)
     val = recv[:, 0, :].reshape(-1)
     keep = idx >= 0
-    out = torch.zeros(K, dtype=local_scores.dtype, device=dev)
     out[idx[keep]] = val[keep].to(local_scores.dtype)
     return out
 

@@ -45,10 +45,12 @@ def parse():
                     help="pairs per launch batch and GPU (4096 x 3.9 MB of key high words = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--path", choices=("fast", "fast32", "fast_f64", "staged"), default="fast",
-                    help="fast: fused CSM+sliding kernel writing two uint32 planes, selection on the high words (the "
-                         "product path); fast_f64: the same with a float64 matrix in between; staged: one kernel per "
-                         "reference function")
+    ap.add_argument("--path", choices=("fast32", "fast", "fast_f64", "fused", "staged"), default="fast32",
+                    help="fast32 (the product path): CSM + sliding window in float32 on the matrix cores, float32 keys, "
+                         "selection with exact float64 refinement of the rows / columns inside the error band (results "
+                         "identical to float64); fast: the same chain with float64 windowed sums (key high words); "
+                         "fast_f64: a float64 matrix in between; fused: masks from the band kernel, no matrix in HBM "
+                         "(csrc/band_kernels.hip); staged: one kernel per reference function")
     ap.add_argument("--overlap", action="store_true",
                     help="fast path: run the alignment sweep of batch b on a second HIP stream while the main "
                          "stream computes batch b+1 (measured: no gain, the sweep's registers/LDS crowd the CUs)")
@@ -57,7 +59,8 @@ def parse():
     return ap.parse_args()
 
 
-STAGES = {"fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
+STAGES = {"fused": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
+          "fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "fast32": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "fast_f64": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
           "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
@@ -240,8 +243,28 @@ class Runner(object):
         mark(5)
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through torch.distributed.run
+    as a CHILD process -- nothing in this process has touched the GPU yet -- and pass rank 0's JSON line through."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus < 1:
+        sys.exit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args))
     import torch
     import torch.distributed as dist
     from acoss_amd import engine, sharding, synth
@@ -249,8 +272,8 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and rank == 0:
-        print("warning: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world), file=sys.stderr)
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, world))
     # one rank per GPU over RCCL (backend "nccl").  ACOSS_BENCH_DIST_BACKEND=gloo is a rehearsal mode for boxes with
     # fewer GPUs than ranks: ranks share the visible devices and the gather goes through host memory.
     backend = os.environ.get("ACOSS_BENCH_DIST_BACKEND", "nccl")

@@ -16,8 +16,11 @@
  *      reference has no FFI for these (they are numpy); they are what a GPU port of
  *      Serra09.similarity (Serra09.py:158-196) calls instead.
  *
- *  (3) The fused per-batch scorer acoss_serra09_scores(): features in, chroma_qmax /
- *      chroma_dmax scores out, nothing materialised in HBM but bit-packed masks.
+ *  (3) The whole chain in one call: acoss_corpus_create() puts a feature set into HBM,
+ *      acoss_serra09_scores() takes a pair list through planning, OTI, cross-similarity +
+ *      sliding window, mutual kNN masks and the alignment recurrences, and returns
+ *      chroma_qmax / chroma_dmax (/ constrained Smith-Waterman) scores divided by (M + N):
+ *      what Serra09.similarity (Serra09.py:161-184) computes per feature type.
  *
  * Conventions: every function returns 0 on success or a negative errno-style code
  * (ACOSS_E*); acoss_last_error() gives the message for the calling thread.  Nothing here
@@ -371,6 +374,41 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                           double kappa, double mu, int niters, void *scratch, size_t scratch_bytes,
                           const acoss_pair_desc *dout, double *cross_out, double *debug_W, double *debug_fused,
                           void *stream);
+
+/* ---------------------------------------------------------------------------------------
+ * (3) the chain in one call
+ * ------------------------------------------------------------------------------------- */
+/* A feature set resident in HBM: the songs of one feature type of Serra09.load_features' dict (Serra09.py:154), frames-
+ * major.  acoss_corpus_create takes HOST arrays -- feats (total_frames x d float64, songs back to back), frame_off
+ * (n_songs + 1 frame offsets), gchroma (n_songs x nbins float64 global chroma, Serra09.py:24-28; NULL for features
+ * without OTI) -- uploads them, forms the per-frame norms and the centred float32 copy the matrix-core kernels use, and
+ * owns that device memory until acoss_corpus_destroy.  acoss_corpus_wrap builds the same handle around arrays the
+ * caller already holds on the DEVICE (f32 / n32: the corpus minus its mean, times a power of two, rounded to float32,
+ * and its squared norms; norms_scaled: those norms in float64 on the HOST; all three NULL: float64 kernels only); the
+ * caller keeps ownership.  One call at a time per handle (it owns the pinned staging of acoss_serra09_scores). */
+typedef struct acoss_corpus acoss_corpus;
+int acoss_corpus_create(const double *feats, const int64_t *frame_off, int n_songs, int d, const double *gchroma,
+                        int nbins, acoss_corpus **out);
+int acoss_corpus_wrap(const double *feats, const double *norms, const double *gchroma, int nbins, const float *f32,
+                      const float *n32, const double *norms_scaled, const int64_t *frame_off, int n_songs, int d,
+                      acoss_corpus **out);
+void acoss_corpus_destroy(acoss_corpus *c);
+
+/* Serra09.py:161-184 for K pairs (pairs[K][2] song indices, HOST): per pair OTI (do_oti; CRPUtils.py:109) -> get_csm
+ * (:67) -> sliding_csm (:24, window win) -> csm_to_binary_mutual (:201, kappa) -> the recurrences asked for in `want`
+ * (bit 0: qmax_c, bit 1: dmax_c on the D qmax leaves behind as Serra09.py:173-175 drives it, bit 2:
+ * swalignimpconstrained), each divided by (M + N) into its HOST output array (float64, position = position in `pairs`;
+ * arrays of recurrences not asked for may be NULL).  Pairs are split by size class (matrices up to 1024 x 1024: float32
+ * filter + exact float64 refinement, identical to float64; up to 2048 x 2048: float64 key high words; beyond, or feature
+ * widths / windows without a fused kernel: one kernel per function with a byte mask) and run in batches of batch_pairs
+ * (<= 0: sized from the song lengths, ~4096 pairs of 1000-frame songs); host planning of a batch overlaps the GPU work of
+ * the one before it, and the call synchronises `stream` once, before it returns.  scratch: DEVICE memory,
+ * acoss_serra09_scratch_bytes() of the same arguments.  Errors: ACOSS_EINVAL (bad indices, a song shorter than win,
+ * scratch too small), ACOSS_EIO. */
+size_t acoss_serra09_scratch_bytes(const acoss_corpus *c, const int32_t *pairs, int K, int win, int batch_pairs);
+int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, double kappa, int do_oti, int want,
+                         int batch_pairs, void *scratch, size_t scratch_bytes, double *qmax, double *dmax, double *swc,
+                         void *stream);
 
 #ifdef __cplusplus
 }

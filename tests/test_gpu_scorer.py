@@ -1,0 +1,109 @@
+"""The one-call scorer of the C ABI (include/acoss_mi355x.h group (3): acoss_corpus_create + acoss_serra09_scores) driven
+through raw ctypes -- no engine, no torch tensors in the call -- against the CPU oracle: the binding a non-Python host
+would write (INTEGRATION.md level 2)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import torch
+    assert torch.cuda.is_available()
+    from acoss_amd import _lib
+    return _lib.load()
+
+
+def _scores(lib, feats, frame_off, gchroma, pairs, want=3, m=9, kappa=0.095, do_oti=1, batch_pairs=0):
+    import torch
+    feats = np.ascontiguousarray(feats, dtype=np.float64)
+    frame_off = np.ascontiguousarray(frame_off, dtype=np.int64)
+    pairs = np.ascontiguousarray(pairs, dtype=np.int32)
+    K = len(pairs)
+    h = ctypes.c_void_p()
+    g = np.ascontiguousarray(gchroma, dtype=np.float64) if gchroma is not None else None
+    rc = lib.acoss_corpus_create(feats.ctypes.data, frame_off.ctypes.data, len(frame_off) - 1, feats.shape[1],
+                                 g.ctypes.data if g is not None else None, g.shape[1] if g is not None else 0, ctypes.byref(h))
+    assert rc == 0, lib.acoss_last_error()
+    try:
+        need = lib.acoss_serra09_scratch_bytes(h, pairs.ctypes.data, K, m, batch_pairs)
+        assert need > 0, lib.acoss_last_error()
+        scratch = torch.empty(need, dtype=torch.uint8, device="cuda")       # any device allocation will do
+        out = [np.full(K, np.nan) for _ in range(3)]
+        rc = lib.acoss_serra09_scores(h, pairs.ctypes.data, K, m, float(kappa), do_oti, want, batch_pairs,
+                                      ctypes.c_void_p(scratch.data_ptr()), need,
+                                      out[0].ctypes.data if want & 1 else None, out[1].ctypes.data if want & 2 else None,
+                                      out[2].ctypes.data if want & 4 else None, None)
+        assert rc == 0, lib.acoss_last_error()
+        return out
+    finally:
+        lib.acoss_corpus_destroy(h)
+
+
+def test_scorer_on_ragged_pairs_equals_oracle(lib, orc):
+    """4000 random pairs (both orientations) of a 350-song corpus with lengths 60..1032, in batches of 1500."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(3)
+    ch = synth.make_corpus(40, 8, seed=3, singletons=30, lengths=lambda r: int(np.clip(r.normal(520, 160), 60, 1032)))
+    allp = synth.all_pairs(ch.n_songs)
+    pairs = allp[rng.permutation(len(allp))[:4000]]
+    pairs = np.where(rng.random((len(pairs), 1)) < 0.5, pairs, pairs[:, ::-1]).astype(np.int32)
+    q, d, _ = _scores(lib, ch.feats, ch.frame_off, ch.gchroma, pairs, want=3, batch_pairs=1500)
+    qo, do, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=min(os.cpu_count() or 1, 16))
+    assert np.array_equal(q, qo) and np.array_equal(d, do)
+
+
+def test_scorer_size_classes_and_smith_waterman(lib, orc):
+    """Songs of 400 .. 3000 frames in one call: the three size classes each take their own kernels; qmax / dmax equal the
+    oracle's, swalignimpconstrained within 1e-5 (its -0.7 penalty is inexact, SequenceAlignment.c:46)."""
+    from acoss_amd import synth
+    lens_it = iter([2300, 400, 1500, 3000, 900])
+    ch = synth.make_corpus(5, 1, seed=99, lengths=lambda r: next(lens_it))
+    pairs = np.array([(0, 1), (1, 0), (2, 4), (3, 0), (4, 4), (1, 1), (4, 2), (1, 4)], dtype=np.int32)
+    q, d, s = _scores(lib, ch.feats, ch.frame_off, ch.gchroma, pairs, want=7)
+    for t, (i, j) in enumerate(pairs):
+        X, Y = ch.song(i), ch.song(j)
+        qo, do = orc.serra09_pair(X, ch.gchroma[i], Y, ch.gchroma[j])
+        assert q[t] == qo and d[t] == do, (t, i, j)
+        if t in (1, 2, 7):
+            B = orc.csm_to_binary_mutual(orc.sliding_csm(orc.get_csm(X, Y, orc.get_oti(ch.gchroma[i], ch.gchroma[j])), 9), 0.095)
+            M, N = B.shape
+            D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+            so = orc.swconstrained(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N)
+            assert abs(s[t] - so) <= 1e-5, (t, s[t], so)
+
+
+def test_scorer_other_widths_windows_and_errors(lib, orc):
+    """20-dimensional features and a window of 5 have no fused kernel: one kernel per function, all three recurrences
+    (the advisor's case: a silent zero for swc there).  Bad indices and short songs are errors, not zeros."""
+    rng = np.random.default_rng(8)
+    lens = [90, 140, 33]
+    feats = rng.random((sum(lens), 20))
+    off = np.concatenate([[0], np.cumsum(lens)])
+    pairs = np.array([(0, 1), (1, 2), (2, 0)], dtype=np.int32)
+    q, d, s = _scores(lib, feats, off, None, pairs, want=7, m=5, kappa=0.1, do_oti=0)
+    for t, (i, j) in enumerate(pairs):
+        X, Y = feats[off[i]:off[i + 1]], feats[off[j]:off[j + 1]]
+        B = orc.csm_to_binary_mutual(orc.sliding_csm(orc.get_csm(X, Y, 0), 5), 0.1)
+        M, N = B.shape
+        Bf = np.ascontiguousarray(B.flatten())
+        D = np.zeros(M * N, dtype=np.float32)
+        assert q[t] == orc.qmax(Bf, D, M, N) / (M + N)
+        assert d[t] == orc.dmax(Bf, D, M, N) / (M + N)          # on the D qmax left behind (Serra09.py:173-175)
+        D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        assert abs(s[t] - orc.swconstrained(Bf, D, M, N) / (M + N)) <= 1e-5 and s[t] > 0
+    h = ctypes.c_void_p()
+    f64 = np.ascontiguousarray(feats)
+    o64 = np.ascontiguousarray(off, dtype=np.int64)
+    assert lib.acoss_corpus_create(f64.ctypes.data, o64.ctypes.data, 3, 20, None, 0, ctypes.byref(h)) == 0
+    bad = np.array([[0, 7]], dtype=np.int32)
+    assert lib.acoss_serra09_scratch_bytes(h, bad.ctypes.data, 1, 5, 0) == 0 and b"names song" in lib.acoss_last_error()
+    short = np.array([[0, 2]], dtype=np.int32)
+    assert lib.acoss_serra09_scratch_bytes(h, short.ctypes.data, 1, 40, 0) == 0 and b"shorter" in lib.acoss_last_error()
+    one = np.zeros(1)
+    assert lib.acoss_serra09_scores(h, pairs.ctypes.data, 1, 5, 0.1, 1, 1, 0, None, 0, one.ctypes.data, None, None, None) == -22
+    lib.acoss_corpus_destroy(h)
