@@ -13,13 +13,18 @@ the score vectors closes the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant HBM-bound kernel of the timed
-path -- the cross-similarity kernel: fused with the sliding window in the default fast path,
-materialising the CSM in `--path staged` -- timed live with HIP events on the launch stream inside
-the timed region (`stage_ms` has every stage).  `roofline_csm_materialising` is the stand-alone
-get_csm kernel on the same batch, measured outside the timed region.  `cpu_baseline` is the CPU
-oracle's same chain timed on the host cores (rank 0, N=1 only); `parity` says whether the GPU scores
-of the sampled pairs are identical to the oracle's.
+Without a launcher (`WORLD_SIZE` unset) and N > 1 the parent process starts the N ranks itself, as a child
+torch.distributed.run, before anything touches the GPU.  A `--gpus` that disagrees with the launcher's world size is
+an error.
+
+Prints ONE JSON line on rank 0.  `roofline` describes the dominant HBM-bound kernel of the timed path -- the
+cross-similarity + sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region
+(`stage_ms` has every stage).  Beside the headline (rank 0, one GPU; `--no-extras` skips them):
+`roofline_csm_*` = the stand-alone get_csm kernels; `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores
+and whether the GPU scores of the sampled pairs are identical; `f64_path` = the same steps with every windowed sum in
+float64 (scores must be identical); `fused` = the same steps with the masks from the fused band kernel; `plugin` = pairs/s
+through the one-call scorer (`engine.serra09_scores`); `config3`, `early_snf`, `ftm2d` = BASELINE configs 3-5 on small
+samples, each with the oracle's CPU rate and an identity check.
 """
 import argparse
 import json
@@ -33,7 +38,9 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+F32_MATRIX_PEAK_TFLOPS = 157.3  # v_mfma_f32_16x16x4_f32 (= the float32 vector peak), same guide
+F64_MATRIX_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 128 flop / clk / CU x 256 CUs x 2.4 GHz
 
 
 def parse():
@@ -42,7 +49,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs-per-step", type=int, default=4096,
-                    help="pairs per launch batch and GPU (4096 x 3.9 MB of key high words = 16 GB of the 288 GB)")
+                    help="pairs per launch batch and GPU (4096 x 3.9 MB of keys = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
     ap.add_argument("--path", choices=("fast32", "fast", "fast_f64", "fused", "staged"), default="fast32",
@@ -51,82 +58,64 @@ def parse():
                          "identical to float64); fast: the same chain with float64 windowed sums (key high words); "
                          "fast_f64: a float64 matrix in between; fused: masks from the band kernel, no matrix in HBM "
                          "(csrc/band_kernels.hip); staged: one kernel per reference function")
-    ap.add_argument("--overlap", action="store_true",
-                    help="fast path: run the alignment sweep of batch b on a second HIP stream while the main "
-                         "stream computes batch b+1 (measured: no gain, the sweep's registers/LDS crowd the CUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="headline only (no comparison paths, no config 3-5 blocks)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = auto)")
     return ap.parse_args()
 
 
-STAGES = {"fused": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
-          "fast": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
-          "fast32": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
-          "fast_f64": ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"],
-          "staged": ["oti", "csm", "sliding", "binarize", "qmax"]}
+STAGES = {p: ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"] for p in ("fast32", "fast", "fast_f64", "fused")}
+STAGES["staged"] = ["oti", "csm", "sliding", "binarize", "qmax"]
 
 
 class Runner(object):
-    """One step, fast path: OTI -> pack_x -> crp (fused CSM + sliding window, squared) -> mask_bits (row and
-    column kNN selection emitting bit vectors by ballot, transposed and ANDed into a 124 KB bit mask per pair)
-    -> qmax from the bits.  Staged path: OTI -> CSM -> sliding ->
-    binarise (thresholds + mask) -> qmax, one kernel per reference function.  All buffers are
-    preallocated and every launch goes to torch's current stream; HIP events between the stages give
-    per-stage times of the timed steps."""
+    """One step.  fast32 / fast: OTI -> pack_x -> crp (CSM + sliding window in one kernel; float32 keys or float64 key high
+    words) -> mask_bits (row and column kNN selection emitting bit vectors by ballot, refinement, transposed and ANDed into
+    a 124 KB bit mask per pair) -> qmax from the bits.  fused: the masks from the band kernel.  staged: OTI -> CSM ->
+    sliding -> binarise -> qmax, one kernel per reference function.  All buffers are preallocated and every launch goes to
+    torch's current stream; HIP events between the stages give per-stage times of the timed steps."""
 
-    def __init__(self, corpus, batches, m, kappa, path, overlap=True):
+    def __init__(self, corpus, batches, m, kappa, path):
         import torch
         from acoss_amd import engine
         self.engine, self.torch, self.path = engine, torch, path
-        # fast path: the alignment sweep (latency-bound: 992 serial row steps, ~15 % VALU) of batch b runs
-        # on a second HIP stream while the main stream already computes batch b+1 (two sets of T/threshold
-        # buffers, events both ways)
-        self.overlap = False
-        # "fast": T leaves the strip kernel as two uint32 planes (key high / low words) and the selections read
-        # only the high-word plane; "fast_f64": T as float64, selections read 8 bytes per element
-        # "fast32": the strip kernel computes a float32 approximation (float32 keys); rows / columns whose k-th smallest
-        # has another value inside the error band are finished in float64: identical masks and scores
-        self.p32 = path == "fast32"
-        if self.p32:
-            path = self.path = "fast"
-        self.planar = path == "fast" and all(engine.planar_supported(corpus, b) for b in batches)
-        self.p32 = self.p32 and self.planar
-        if path == "fast_f64":
-            path = self.path = "fast"
         self.corpus, self.m, self.kappa = corpus, m, kappa
         dev = corpus.device
         lib = engine._lib.load()
+        bits_ok = all(engine.planar_supported(corpus, b) for b in batches)
+        if path in ("fast32", "fast") and not bits_ok:
+            raise SystemExit("bench.py: --path %s needs float64 12 / 13-bin features and songs up to 2056 frames" % path)
+        if path == "fused" and not all(engine.fused_supported(corpus, b) for b in batches):
+            raise SystemExit("bench.py: --path fused needs float64 12 / 13-bin features and songs up to 1022 frames")
+        self.planar = path in ("fast32", "fast")
         tr = max(b.total_crp for b in batches)
-        # the big intermediate: float64 sums (8 B / cell), or their key high words on the fast path (4 B / cell)
-        s_elems = (tr // 2 + 32) if self.planar else (tr + 32)
-        self.S = torch.empty(s_elems, dtype=torch.float64, device=dev)
-        self.B = torch.zeros(tr, dtype=torch.uint8, device=dev) if path == "staged" else None
-        if path == "staged":
-            self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
-        else:
+        self.bits = None
+        if path in ("fast32", "fast", "fast_f64", "fused"):
+            self.bits = torch.zeros(max(b.K * (b.max_nx - m + 1) * engine.bits_words(b) for b in batches), dtype=torch.int64, device=dev)
+        if path in ("fast32", "fast", "fast_f64"):
+            s_elems = (tr // 2 + 32) if self.planar else (tr + 32)
+            self.S = torch.empty(s_elems, dtype=torch.float64, device=dev)
             self.xp = torch.empty(max(int(lib.acoss_xpack_elems(b.K, b.max_nx)) for b in batches),
-                                  dtype=corpus.feats.dtype, device=dev)
-        if path == "fast":
+                                  dtype=torch.float32 if path == "fast32" else corpus.feats.dtype, device=dev)
             need = max(int(lib.acoss_mask_bits_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
-            self.bits = torch.zeros(max(b.K * (b.max_nx - m + 1) * 16 for b in batches), dtype=torch.int64, device=dev)
+            self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        elif path == "fused":
+            self.side_rows = max(engine.fused_side_rows(b) for b in batches)
+            need = max(int(lib.acoss_mask_bits_fused_work_bytes(b.K, b.max_nx, b.max_ny, m, self.side_rows)) for b in batches)
+            self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+            engine.packed32(corpus)
         else:
+            self.S = torch.empty(tr + 32, dtype=torch.float64, device=dev)
+            self.B = torch.zeros(tr, dtype=torch.uint8, device=dev)
+            self.C = torch.empty(max(b.total_csm for b in batches), dtype=corpus.feats.dtype, device=dev)
             need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
-        self.work = torch.empty(need, dtype=torch.uint8, device=dev)
-        if self.p32:
-            self.xp32 = torch.empty(self.xp.numel(), dtype=torch.float32, device=dev)
-            self.bands = [engine.planar32_band(corpus, b) for b in batches]
+            self.work = torch.empty(need, dtype=torch.uint8, device=dev)
+        self.bands = None
+        if path == "fast32":
             engine.float32_copy(corpus)
-        # --overlap: the alignment sweep (latency-bound: 992 serial row steps, one wave per pair, 124 KB of mask per
-        # pair) of batch b runs on a second HIP stream while the main stream already builds batch b + 1 (two mask
-        # buffers, events both ways)
-        self.overlap = bool(overlap) and self.planar
-        if self.overlap:
-            # two copies of the high-word matrix: the strip kernel of batch b + 1 (LDS / barrier-bound) runs on the main
-            # stream while the selection + alignment kernels of batch b (HBM / latency-bound) run on the side stream
-            self.S2 = [self.S, torch.empty(s_elems, dtype=torch.float64, device=dev)]
-            self.side = torch.cuda.Stream(device=dev)
-            self.ready = [torch.cuda.Event(), torch.cuda.Event()]
-            self.free = [torch.cuda.Event(), torch.cuda.Event()]
+            self.bands = [engine.planar32_band(corpus, b) for b in batches]
+        if path == "fused":
+            self.bands = [engine.planar32_band(corpus, b, fused=True) for b in batches]
         # The strip kernel's time depends on which allocation it writes (DESIGN.md section 4: 3.9 vs 4.4 ms for two
         # 16 GB buffers in one process, any offset inside either gives the same time).  Try a few placements for
         # the big intermediate once, before anything is timed, and keep the fastest.
@@ -134,11 +123,10 @@ class Runner(object):
         if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
             b0 = batches[0]
             engine.oti(corpus, b0)
-            engine.pack_x(corpus, b0, out=self.xp)
             cands, times = [self.S], []
             try:
                 for _ in range(2):
-                    cands.append(torch.empty(s_elems, dtype=torch.float64, device=dev))
+                    cands.append(torch.empty(self.S.numel(), dtype=torch.float64, device=dev))
             except RuntimeError:
                 pass
             for buf in cands:
@@ -147,34 +135,37 @@ class Runner(object):
                 for rep in range(3):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    if self.p32:
-                        engine.crp_planar32(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp32), out=planes)
+                    if path == "fast32":
+                        engine.crp_planar32(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp), out=planes)
                     else:
-                        engine.crp_planar(corpus, b0, self.xp, out=planes)
+                        engine.crp_planar(corpus, b0, engine.pack_x(corpus, b0, out=self.xp), out=planes)
                     e1.record()
                     torch.cuda.synchronize()
                     if rep:
                         best = min(best, e0.elapsed_time(e1))
                 times.append(best)
             self.S = cands[int(np.argmin(times))]
-            if self.overlap:
-                self.S2[0] = self.S
             self.placement_ms = [round(t, 3) for t in times]
             del cands
             torch.cuda.empty_cache()
         self.plans = []
         for b in batches:
-            mats, _ = b.mats()
-            self.plans.append((b, mats, engine.to_device_bytes(mats, dev), int(mats["cols"].max())))
+            if path == "staged":
+                mats, _ = b.mats()
+                self.plans.append((b, mats, engine.to_device_bytes(mats, dev), int(mats["cols"].max())))
+            else:
+                self.plans.append((b, None, None, 0))
         es = corpus.feats.element_size()
         nx = [b.descs["nx"].astype(np.float64) for b in batches]
         ny = [b.descs["ny"].astype(np.float64) for b in batches]
         # algorithmic bytes per launch of the cross-similarity kernel of each path
         self.csm_bytes = [float(np.sum(es * (x * y + corpus.d * (x + y)))) for x, y in zip(nx, ny)]
-        # the fast path's strip kernel writes 4 bytes per cell (key high words), the float64 form 8
-        cell = 4.0 if self.planar else 8.0
-        fes = 4 if self.p32 else es
+        cell = 4.0 if self.planar else 8.0          # keys (4 B / cell) or a float64 matrix
+        fes = 4 if path == "fast32" else es
         self.crp_bytes = [float(np.sum(cell * (x - m + 1) * (y - m + 1) + fes * corpus.d * (x + y))) for x, y in zip(nx, ny)]
+        # the fused band kernel: float32 multiply-adds of the distance products it forms (both orientations, 32 C rows
+        # per 24-row band, contraction depth d + 2)
+        self.band_flops = [float(np.sum(2.0 * (corpus.d + 2) * (32.0 / 24.0) * 2.0 * (x - m + 1) * y)) for x, y in zip(nx, ny)]
 
     def step(self, i, scores_out, ev=None):
         e = self.engine
@@ -183,60 +174,44 @@ class Runner(object):
         def mark(k):
             if ev is not None:
                 ev[k].record()
-        if self.overlap:
-            torch = self.torch
-            slot = i & 1
-            main = torch.cuda.current_stream()
-            main.wait_event(self.free[slot])          # the selection that last read this copy has finished
-            mark(0)
-            e.oti(self.corpus, b)
-            mark(1)
-            e.pack_x(self.corpus, b, out=self.xp)
-            mark(2)
-            planes = self.S2[slot].view(torch.int32)[:e.planar_elems(b)]
-            e.crp_planar(self.corpus, b, self.xp, out=planes)
-            mark(3)
-            self.ready[slot].record(main)
-            with torch.cuda.stream(self.side):
-                self.side.wait_event(self.ready[slot])
-                e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
-                mark(4)
-                e.align_bits("qmax", self.bits, b, scores=scores_out)
-                mark(5)
-                self.free[slot].record(self.side)
-            return
         mark(0)
         e.oti(self.corpus, b)
         mark(1)
-        if self.path == "fast":
-            if self.p32:
-                e.pack_x32(self.corpus, b, out=self.xp32)
+        if self.path == "fused":
+            mark(2)
+            mark(3)
+            e.mask_bits_fused(self.corpus, b, self.kappa, band=self.bands[i], out=self.bits, work=self.work,
+                              side_rows=self.side_rows, verify=False)
+            mark(4)
+            e.align_bits("qmax", self.bits, b, scores=scores_out)
+        elif self.path in ("fast32", "fast", "fast_f64"):
+            if self.path == "fast32":
+                e.pack_x32(self.corpus, b, out=self.xp)
             else:
                 e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            if self.p32:
+            if self.path == "fast32":
                 planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
-                e.crp_planar32(self.corpus, b, self.xp32, out=planes)
-            elif self.planar:
+                e.crp_planar32(self.corpus, b, self.xp, out=planes)
+            elif self.path == "fast":
                 planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
                 e.crp_planar(self.corpus, b, self.xp, out=planes)
             else:
                 e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)
-        else:
-            e.csm(self.corpus, b, out=self.C)
-            mark(2)
-            e.sliding(self.C, b, out=self.S)
-        mark(3)
-        if self.path == "fast":
-            if self.p32:
+            mark(3)
+            if self.path == "fast32":
                 e.mask_bits_planar32(planes, self.bands[i], self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
-            elif self.planar:
+            elif self.path == "fast":
                 e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
             else:
                 e.mask_bits(self.S, b, self.kappa, True, out=self.bits, work=self.work)
             mark(4)
             e.align_bits("qmax", self.bits, b, scores=scores_out)
         else:
+            e.csm(self.corpus, b, out=self.C)
+            mark(2)
+            e.sliding(self.C, b, out=self.S)
+            mark(3)
             e.binarize(self.S, b, self.kappa, True, out=self.B, work=self.work)
             mark(4)
             e.align("qmax", self.B, mats, mats_dev=mats_dev, max_cols=max_cols, scores=scores_out)
@@ -245,7 +220,7 @@ class Runner(object):
 
 def launch_ranks(args):
     """`python bench.py --gpus N` without a launcher: start N ranks (one process per GPU) through torch.distributed.run
-    as a CHILD process -- nothing in this process has touched the GPU yet -- and pass rank 0's JSON line through."""
+    as a CHILD process -- nothing in this process has touched the GPU -- and pass rank 0's JSON line through."""
     import socket
     import subprocess
     s = socket.socket()
@@ -257,6 +232,146 @@ def launch_ranks(args):
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     return subprocess.call(cmd, env=env)
+
+
+def timed_steps(runner, n_steps, warmup, P, dev, torch):
+    """warmup untimed steps, then the timed ones with per-stage events; returns (seconds, scores tensor, stage_ms)."""
+    scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
+    events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
+    for s in range(warmup):
+        runner.step(s, scores[s])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, n_steps):
+        runner.step(s, scores[s], events[s])
+    scores[warmup:].reshape(-1).cpu()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    names = STAGES[runner.path]
+    stage_ms = {names[k]: round(float(np.mean([events[s][k].elapsed_time(events[s][k + 1]) for s in range(warmup, n_steps)])), 4)
+                for k in range(5)}
+    return el, scores, stage_ms
+
+
+def time_kernel(fn, torch, reps=5):
+    ms = []
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1))
+    return float(np.median(ms[1:]))
+
+
+def pmc_traffic(path, kernel_key, P, frames):
+    """HBM bytes per launch of the path's dominant kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE
+    exact, FETCH_SIZE x 2 on gfx950) -- only quoted when the profile was taken on this very workload."""
+    for name in ("r02_%s_pmc.json" % path, "r01_final_pmc.json"):
+        f = os.path.join(ROOT, "profiles", name)
+        if not os.path.exists(f) or frames != 1000:
+            continue
+        with open(f) as fh:
+            doc = json.load(fh)
+        c = doc.get(kernel_key)
+        if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
+            return (round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9),
+                    "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)" % name)
+    return None, None
+
+
+def extras_config3(engine, synth, oracle, threads, torch):
+    """BASELINE config 3 (DA-TACOS benchmark_subset shape, Serra09 with constrained Smith-Waterman): a 2000-song sample of
+    synth.config3's distribution, qmax + dmax + swc through the one-call scorer."""
+    ch = synth.config3(n_cliques=133, singletons=271)
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    rng = np.random.default_rng(1)
+    allp = synth.all_pairs(ch.n_songs)
+    pairs = allp[rng.permutation(len(allp))[:32768]]
+    engine.serra09_scores(corpus, pairs, want=("qmax", "dmax", "swc"))       # warm: scratch of the final size, float32 copy
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = engine.serra09_scores(corpus, pairs, want=("qmax", "dmax", "swc"))
+    el = time.perf_counter() - t0
+    n_cpu = min(32 * threads, len(pairs))
+    t0 = time.perf_counter()
+    q, d, used = oracle.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs[:n_cpu], nthreads=threads)
+    cpu_s = time.perf_counter() - t0
+    # swalignimpconstrained on the oracle's mask of a few pairs (its float32 sums carry a -0.7: 1e-5 tolerance)
+    sw_err = 0.0
+    for t in range(4):
+        i, j = pairs[t]
+        B = oracle.csm_to_binary_mutual(oracle.sliding_csm(oracle.get_csm(ch.song(int(i)), ch.song(int(j)), oracle.get_oti(ch.gchroma[i], ch.gchroma[j])), 9), 0.095)
+        M, N = B.shape
+        D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        sw_err = max(sw_err, abs(got["swc"][t] - oracle.swconstrained(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N)))
+    return {"workload": "%d songs (synth.config3 distribution: cliques of 13 + singletons, lengths ~N(520,120) in [200,1200]), "
+                        "%d random pairs, Serra09 qmax + dmax + constrained Smith-Waterman (EarlySNF_Old.py:198-218) per pair" % (ch.n_songs, len(pairs)),
+            "value": round(len(pairs) / el, 1), "unit": "pair-scores/s (3 recurrences per pair)", "seconds": round(el, 3),
+            "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "pair-scores/s (qmax + dmax)", "cores": int(used), "kind": "port",
+                             "sample": "%d of the pairs through oracle/acoss_oracle.c" % n_cpu},
+            "parity": {"qmax_dmax_identical": bool(np.array_equal(got["qmax"][:n_cpu], q) and np.array_equal(got["dmax"][:n_cpu], d)),
+                       "swc_max_abs_err_4_pairs": float(sw_err), "swc_tolerance": 1e-5}}
+
+
+def extras_early_snf(engine, synth, torch):
+    """BASELINE config 4: EarlySNF (EarlySNF.py:35-97) on 1000-frame songs, chroma + 64-d stand-ins for the scattering
+    features (kymatio is absent), 3 cross-diffusion iterations; the float64 products run on v_mfma_f64_16x16x4_f64."""
+    from oracle import snf as osnf
+    ch = synth.make_corpus(4, 4, n_frames=1000, seed=20260)
+    rng = np.random.default_rng(0)
+    chroma = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    ss = [np.cumsum(rng.standard_normal((992, 64)), axis=0) * 0.1 for _ in range(ch.n_songs)]
+    ssms = engine.DeviceCorpus(np.concatenate(ss), np.arange(ch.n_songs + 1, dtype=np.int64) * 992)
+    allp = synth.all_pairs(ch.n_songs)
+    K = 32
+    pairs = allp[np.arange(K) % len(allp)]
+    engine.early_snf_scores(chroma, ssms, pairs[:4])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = engine.early_snf_scores(chroma, ssms, pairs)
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    gflop = 12.0 * 2.0 * 1984.0 ** 3 / 1e9          # 2 features x 3 iterations x 2 products of 1984^3
+    i, j = pairs[0]
+    t0 = time.perf_counter()
+    qo, do = osnf.early_snf_pair({"gchroma": ch.gchroma[i], "chroma": ch.song(int(i)).T, "ssms": ss[i]},
+                                 {"gchroma": ch.gchroma[j], "chroma": ch.song(int(j)).T, "ssms": ss[j]})
+    cpu_s = time.perf_counter() - t0
+    return {"workload": "%d pairs of 1000-frame songs (fused matrices of 1984 x 1984, %d GFLOP of float64 products per pair)" % (K, round(gflop)),
+            "value": round(K / el, 1), "unit": "pairs/s", "seconds": round(el, 3),
+            "f64_tflops_end_to_end": round(gflop * K / el / 1e3, 1), "frac_of_f64_matrix_peak": round(gflop * K / el / 1e3 / F64_MATRIX_PEAK_TFLOPS, 3),
+            "cpu_baseline": {"value": round(1.0 / cpu_s, 3), "unit": "pairs/s", "cores": "numpy BLAS threads", "kind": "port",
+                             "sample": "1 pair through oracle/snf.py (%.1f s)" % cpu_s},
+            "parity": {"checked_pairs": 1, "identical": bool(res["qmax"][0] == qo and res["dmax"][0] == do)}}
+
+
+def extras_ftm2d(engine, torch):
+    """BASELINE config 5: FTM2D (FTM2D.py:118-130) -- all N^2 similarities exp(-|s_i - s_j|^2) of 900-d shingles as one
+    N x 900 x N float64 product on the matrix cores, N = 15 000 (DA-TACOS benchmark_subset size)."""
+    from oracle import ftm2d as oft
+    rng = np.random.default_rng(0)
+    N = 15000
+    X = torch.from_numpy(rng.random((N, 900))).cuda()
+    X /= X.norm(dim=1, keepdim=True)
+    engine.ftm2d_gram(X)
+    ms = time_kernel(lambda: engine.ftm2d_gram(X), torch)
+    G = engine.ftm2d_gram(X)
+    Xh = X[:2000].cpu().numpy()
+    t0 = time.perf_counter()
+    sq = np.sum(Xh * Xh, 1)
+    Gh = np.exp(-(sq[:, None] + sq[None, :] - 2.0 * Xh.dot(Xh.T)))
+    cpu_s = time.perf_counter() - t0
+    ref = np.array([[oft.similarity(Xh[a], Xh[b]) for b in range(8)] for a in range(8)])
+    err = float(np.max(np.abs(G[:8, :8].cpu().numpy() - ref)))
+    del Gh
+    return {"workload": "all %d x %d similarities of 900-d shingles (one float64 product)" % (N, N),
+            "value": round(N * N / ms / 1e6, 2), "unit": "G pair-similarities/s", "ms": round(ms, 3),
+            "f64_tflops": round(2.0 * N * N * 900 / ms / 1e9, 1), "frac_of_f64_matrix_peak": round(2.0 * N * N * 900 / ms / 1e9 / F64_MATRIX_PEAK_TFLOPS, 3),
+            "cpu_baseline": {"value": round(2000 * 2000 / cpu_s / 1e9, 4), "unit": "G pair-similarities/s", "cores": "numpy BLAS threads", "kind": "port",
+                             "sample": "2000 x 2000 block as numpy dgemm + exp (%.2f s)" % cpu_s},
+            "parity": {"max_abs_err_vs_oracle_8x8": err, "tolerance": 1e-12}}
 
 
 def main():
@@ -291,13 +406,15 @@ def main():
     corpus_h = synth.config2(n_songs=args.songs, n_frames=args.frames)
     corpus = engine.DeviceCorpus(corpus_h.feats, corpus_h.frame_off, gchroma=corpus_h.gchroma, device=dev)
     all_pairs = synth.all_pairs(corpus_h.n_songs)
-    mine = sharding.shard_indices(sharding.pair_costs(corpus_h.frame_off, all_pairs, m), world, rank)
+    costs = sharding.pair_costs(corpus_h.frame_off, all_pairs, m)
+    mine = sharding.shard_indices(costs, world, rank)
     P = args.pairs_per_step
     n_steps = args.warmup + args.steps
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
     step_idx = [mine[(np.arange(P) + s * P) % len(mine)] for s in range(n_steps)]
-    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev, pitch_align=32 if args.path in ("fast", "fast32") else 16) for ix in step_idx]
-    runner = Runner(corpus, batches, m, kappa, args.path, overlap=args.overlap)
+    pitch = 16 if args.path in ("fast_f64", "staged") else 32
+    batches = [engine.PairBatch(corpus.frame_off, all_pairs[ix], m, dev, pitch_align=pitch) for ix in step_idx]
+    runner = Runner(corpus, batches, m, kappa, args.path)
     scores = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
 
@@ -313,8 +430,6 @@ def main():
     t0 = time.perf_counter()
     for s in range(args.warmup, n_steps):
         runner.step(s, scores[s], events[s])
-    if runner.overlap:
-        torch.cuda.current_stream().wait_stream(runner.side)
     # the path's only collective: gather every rank's timed scores (RCCL all-gather over xGMI)
     timed_idx = np.concatenate(step_idx[args.warmup:])
     local = scores[args.warmup:].reshape(-1)
@@ -330,7 +445,7 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -339,87 +454,77 @@ def main():
     names = STAGES[args.path]
     stage_ms = {names[k]: float(np.mean([events[s][k].elapsed_time(events[s][k + 1])
                                           for s in range(args.warmup, n_steps)])) for k in range(5)}
-    # dominant HBM-bound kernel of the path: the cross-similarity kernel (fused with the sliding
-    # window in the fast path, materialising the CSM in the staged path)
-    if args.path in ("fast", "fast32", "fast_f64"):
-        kname, kms, kbytes = "crp_strip_kernel<12,9> (CRPUtils.py:67 + :24 fused, f64 MFMA)", stage_ms["crp"], runner.crp_bytes
-    else:
-        kname, kms, kbytes = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
-    kbytes = float(np.mean(kbytes[args.warmup:]))
-    achieved = kbytes / (kms * 1e-3) / 1e9
-
-    # HBM bytes per launch of that kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE exact,
-    # FETCH_SIZE x2 on gfx950) -- only quoted when the profile was taken on this very workload
+    # dominant kernel of the path: the cross-similarity kernel (with the sliding window in the fast paths, materialising
+    # the CSM in the staged path; in the fused path it also holds the selection and is bound by LDS and issue, not HBM:
+    # its line quotes the float32 matrix-core rate of the distance products)
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_final_pmc.json")
-    pmc_key = {"fast": "crp_strip_kernel<12, 9, false, 0, false, true>"}.get(args.path)
-    if pmc_key and runner.planar and args.frames == 1000 and os.path.exists(pmc_file):
-        with open(pmc_file) as fh:
-            doc = json.load(fh)
-        c = doc.get(pmc_key)
-        if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
-            traffic = round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9)
-            traffic_src = "profiles/r01_final_pmc.json (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)"
-    if runner.planar:
-        kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
-    if runner.p32:
-        kname = "crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA approximation, float32 keys out: 4 B / cell; exact f64 refinement in select_fix_planar_kernel)"
+    if args.path == "fused":
+        kms, kwork = stage_ms["mask_bits"], float(np.mean(runner.band_flops[args.warmup:]))
+        achieved, peak, unit, bound = kwork / (kms * 1e-3) / 1e12, F32_MATRIX_PEAK_TFLOPS, "TFLOP/s", "mfma"
+        kname = "crp_band_kernel<12> + band_fix + combine_planes (CRPUtils.py:67 + :24 + :201 fused; f32 MFMA; bound by LDS and issue, see DESIGN.md)"
+    else:
+        key = None
+        if args.path == "staged":
+            kname, kms, kwork = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
+        elif args.path == "fast32":
+            kname = ("crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
+                     "refinement in select_fix_side_kernel)")
+            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip32_kernel<12, 0>"
+        elif args.path == "fast":
+            kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
+            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip_kernel<12, 9, false, 0, false, true>"
+        else:
+            kname, kms, kwork = "crp_strip_kernel<12,9> (CRPUtils.py:67 + :24 fused, f64 MFMA, float64 out)", stage_ms["crp"], runner.crp_bytes
+        kwork = float(np.mean(kwork[args.warmup:]))
+        achieved, peak, unit, bound = kwork / (kms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
+        if key:
+            traffic, traffic_src = pmc_traffic(args.path, key, P, args.frames)
+    dtype = {"fast32": "f32 filter + f64 exact refinement (results identical to f64)",
+             "fused": "f32 filter + f64 exact refinement (results identical to f64)"}.get(args.path, "f64")
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
         "value": round(value, 1), "unit": "pair-scores/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32 filter + f64 exact refinement (results identical to f64)" if runner.p32 else "f64",
-        "data": "synthetic",
+        "dtype": dtype, "data": "synthetic",
         "config": {"workload": "synthetic %d songs x %d frames x 12-bin HPCP (f64), Serra09 chroma_qmax "
                                "m=9 kappa=0.095 OTI, %d pairs/step/GPU of the %d-pair job"
                                % (args.songs, args.frames, P, len(all_pairs)),
-                   "path": args.path, "pairs_per_step_per_gpu": P, "overlap_alignment_stream": bool(runner.overlap),
+                   "path": args.path, "pairs_per_step_per_gpu": P,
                    "output_placement_probe_ms": runner.placement_ms,
                    "parallelism": "pair-shard x%d, one all-gather" % world},
-        "roofline": {"kernel": kname, "bound": "hbm",
-                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                     "bytes_per_launch": kbytes, "avg_launch_ms": round(kms, 4)},
+        "roofline": {"kernel": kname, "bound": bound,
+                     "achieved": round(achieved, 1), "peak": peak, "unit": unit,
+                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     ("flops_per_launch" if bound == "mfma" else "bytes_per_launch"): kwork, "avg_launch_ms": round(kms, 4)},
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
-    if rank == 0 and args.path in ("fast", "fast32", "fast_f64"):
+    extras = rank == 0 and world == 1 and not args.no_extras
+    if extras and args.path in ("fast", "fast32", "fast_f64", "fused"):
         # get_csm as an API (the kernel the north star names) on the same batch, outside the timed
         # region, reported beside the path's own dominant kernel: the plain VALU kernel and the
         # persistent matrix-core strip kernel (bit-identical outputs)
         b = batches[-1]
         C = torch.empty(b.total_csm, dtype=corpus.feats.dtype, device=dev)
         cb = runner.csm_bytes[-1]
-
-        def time_kernel(fn):
-            ms = []
-            for _ in range(5):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                fn()
-                e1.record()
-                torch.cuda.synchronize()
-                ms.append(e0.elapsed_time(e1))
-            return float(np.median(ms[1:]))
-        xp = engine.pack_x(corpus, b, out=runner.xp)
+        xp = engine.pack_x(corpus, b)
         for key, kname2, fn in (("roofline_csm_materialising", "crp_strip_kernel<12,1,sqrt> as get_csm (CRPUtils.py:67), not on the fast path",
                                  lambda: engine.csm_strip(corpus, b, xp, out=C)),
                                 ("roofline_csm_valu", "csm_kernel<double,12> (CRPUtils.py:67), not on the fast path",
                                  lambda: engine.csm(corpus, b, out=C))):
-            cms = time_kernel(fn)
+            cms = time_kernel(fn, torch)
             out[key] = {"kernel": kname2, "bound": "hbm", "achieved": round(cb / cms / 1e6, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(cb / cms / 1e6 / HBM_PEAK_GBS, 4), "bytes_per_launch": cb,
                         "avg_launch_ms": round(cms, 4)}
         # context for those fractions: what a plain streaming store of the same byte count reaches on this GPU
-        # (torch fill_ into the same buffer; 33.5 GB in one launch runs at ~4.7 TB/s, 16 GB at ~6.2 TB/s)
-        fms = time_kernel(lambda: C.fill_(1.0))
+        fms = time_kernel(lambda: C.fill_(1.0), torch)
         fb = C.numel() * C.element_size()
         out["hbm_write_ceiling"] = {"kernel": "torch fill_ of the CSM buffer, %d bytes (plain streaming stores)" % fb,
                                     "achieved": round(fb / fms / 1e6, 1), "unit": "GB/s", "avg_launch_ms": round(fms, 4)}
-        del C
+        del C, xp
+    threads = max(1, min(os.cpu_count() or 1, 16))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
-        threads = max(1, min(os.cpu_count() or 1, 16))
         n_cpu = args.cpu_pairs or min(512 * threads, len(timed_idx))
         sample = all_pairs[timed_idx[:n_cpu]]
         oracle.serra09_pairs(corpus_h.feats, corpus_h.frame_off, corpus_h.gchroma, sample[:threads],
@@ -463,39 +568,58 @@ def main():
                 "sample": "%d x %d calls of the reference's qmax_c (SequenceAlignment.c:113, -Ofast) on %dx%d masks, D zeroed per "
                           "call" % (reps, n_dp, Mn, Mn),
                 "identical_to_gpu": bool(np.array_equal(np.array(q_ref) / denom, gpu_q[:n_dp]))}
-    if rank == 0 and world == 1 and args.path == "fast" and runner.planar and not os.environ.get("ACOSS_BENCH_NO_FAST32"):
-        # beside the float64 line above: the same steps with the float32-filter form of the strip kernel (`--path fast32`);
-        # its scores must equal the float64 path's on every pair of the timed steps
+    if extras:
+        from oracle import oracle
         last = scores[args.warmup:].clone()
         del runner, events
         engine.release_scratch()
-        r32 = Runner(corpus, batches, m, kappa, "fast32", overlap=False)
-        s32 = torch.zeros(n_steps, P, dtype=torch.float32, device=dev)
-        ev32 = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
-        for s_ in range(args.warmup):
-            r32.step(s_, s32[s_])
+        # the same steps through the other compositions of the chain: scores must equal the headline's on every pair
+        for key, other in (("f64_path", "fast"), ("fused", "fused")):
+            if other == args.path or pitch != 32:
+                continue
+            try:
+                r2 = Runner(corpus, batches, m, kappa, other)
+            except SystemExit:
+                continue
+            el2, s2, st2 = timed_steps(r2, n_steps, args.warmup, P, dev, torch)
+            blk = {"path": other, "value": round(args.steps * P / el2, 1), "unit": "pair-scores/s",
+                   "ms_per_step": round(1e3 * el2 / args.steps, 3), "stage_ms": st2,
+                   "scores_identical_to_headline": bool(torch.equal(s2[args.warmup:], last))}
+            if other == "fast":
+                bpl = float(np.mean(r2.crp_bytes[args.warmup:]))
+                blk["dtype"] = "f64"
+                blk["roofline"] = {"kernel": "crp_strip_kernel<12,9,planar> (f64 MFMA, key high words out: 4 B / cell)", "bound": "hbm",
+                                   "achieved": round(bpl / (st2["crp"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(bpl / (st2["crp"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": bpl,
+                                   "avg_launch_ms": st2["crp"]}
+            else:
+                blk["note"] = ("masks from crp_band_kernel (csrc/band_kernels.hip): no matrix in HBM, both orientations recomputed; "
+                               "mask_bits holds CSM + window + selection + refinement + combine")
+            out[key] = blk
+            del r2, s2
+            engine.release_scratch()
+        # pairs/s through the library's one-call scorer (planning, copies and the final synchronisation included)
+        sel = all_pairs[np.random.default_rng(0).permutation(len(all_pairs))[:8 * P]]
+        engine.serra09_scores(corpus, sel, want=("qmax",))         # warm: scratch of the final size
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for s_ in range(args.warmup, n_steps):
-            r32.step(s_, s32[s_], ev32[s_])
-        h32 = s32[args.warmup:].reshape(-1).cpu().numpy()
-        torch.cuda.synchronize()
-        el32 = time.perf_counter() - t0
-        names = STAGES["fast32"]
-        out["fast32"] = {"value": round(args.steps * P / el32, 1), "unit": "pair-scores/s", "ms_per_step": round(1e3 * el32 / args.steps, 3),
-                         "dtype": "f32 filter + f64 exact refinement",
-                         "stage_ms": {names[k]: round(float(np.mean([ev32[s_][k].elapsed_time(ev32[s_][k + 1])
-                                                                       for s_ in range(args.warmup, n_steps)])), 4) for k in range(5)},
-                         "roofline": {"kernel": "crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell)",
-                                      "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                      "bytes_per_launch": float(np.mean(r32.crp_bytes[args.warmup:]))},
-                         "scores_identical_to_f64_path": bool(torch.equal(s32[args.warmup:], last)),
-                         "note": "crp_strip32_kernel + error-band check + float64 refinement (DESIGN.md section 4); same steps, same pairs"}
-    if rank == 0 and "fast32" in out:
-        rf = out["fast32"]["roofline"]
-        rf["avg_launch_ms"] = out["fast32"]["stage_ms"]["crp"]
-        rf["achieved"] = round(rf["bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9, 1)
-        rf["frac"] = round(rf["achieved"] / HBM_PEAK_GBS, 4)
+        got = engine.serra09_scores(corpus, sel, want=("qmax",))
+        el3 = time.perf_counter() - t0
+        out["plugin"] = {"call": "engine.serra09_scores -> acoss_serra09_scores (C ABI), qmax only, %d pairs in one call" % len(sel),
+                         "value": round(len(sel) / el3, 1), "unit": "pair-scores/s", "frac_of_kernel_chain_rate": round(len(sel) / el3 / value, 3)}
+        del got
+        engine.release_scratch()
+        del corpus
+        torch.cuda.empty_cache()
+        for key, fn in (("config3", lambda: extras_config3(engine, synth, oracle, threads, torch)),
+                        ("early_snf", lambda: extras_early_snf(engine, synth, torch)),
+                        ("ftm2d", lambda: extras_ftm2d(engine, torch))):
+            try:
+                out[key] = fn()
+            except Exception as exc:           # a side block must not take the headline down
+                out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            engine.release_scratch()
+            torch.cuda.empty_cache()
     if rank == 0:
         print(json.dumps(out))
     if world > 1:
