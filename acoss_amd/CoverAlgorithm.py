@@ -60,37 +60,43 @@ class CoverAlgorithm(object):
 
     def __init__(self, name="Generic", datapath="features_benchmark", shortname="full", cachedir="cache",
                  cache2dir="cache2", similarity_types=["main"], do_memmaps=True):
-        self.name = name
-        self.shortname = shortname
-        self.cachedir = cachedir
-        self.corpus = None
-        if isinstance(datapath, str):
-            self.filepaths = sorted(glob.glob("%s/*.h5" % datapath))     # CoverAlgorithm.py:41
-            if len(self.filepaths) == 0:
-                self.filepaths = sorted(glob.glob("%s/*.npz" % datapath))
-        else:
-            # an in-memory corpus (acoss_amd.synth.Corpus): synthetic benchmarks and tests
-            self.corpus = datapath
-            self.filepaths = ["<memory>/song_%06d" % i for i in range(self.corpus.n_songs)]
-        self.cliques = {}
-        self.all_feats = {}   # For caching loaded features
-        self.N = len(self.filepaths)
-        self.do_memmaps = do_memmaps
-        self.similarity_types = similarity_types
+        """Same arguments and attributes as CoverAlgorithm.py:28-57 (`cache2dir` is accepted and, as there, unused until
+        set_cache2dir).  `datapath` may also be an in-memory corpus (acoss_amd.synth.Corpus)."""
+        self.name, self.shortname, self.cachedir = name, shortname, cachedir
+        self.similarity_types, self.do_memmaps = similarity_types, do_memmaps
         self.cache2dir = None
+        self.cliques = {}        # label -> set of song indices
+        self.all_feats = {}      # per-song feature cache of the subclasses
+        self.corpus, self.filepaths = self._discover(datapath)
+        self.N = len(self.filepaths)
         if do_memmaps:
-            os.makedirs(cachedir, exist_ok=True)
-            self.Ds = {}
-            # one process per GPU (torch.distributed): the file-backed matrices belong to rank 0, the other ranks keep
-            # theirs in memory (every rank opening the same file with 'w+' would truncate it under the others)
-            owner = int(os.environ.get("RANK", "0")) == 0
-            for s in similarity_types:
-                if owner:
-                    self.Ds[s] = np.memmap('%s_%s_dmat' % (self.get_cacheprefix(), s), shape=(self.N, self.N),
-                                           mode='w+', dtype='float32')
-                else:
-                    self.Ds[s] = np.zeros((self.N, self.N), dtype=np.float32)
+            self.Ds = {s: self._open_matrix(s) for s in similarity_types}
         print("Initialized %s algorithm on %i songs in dataset %s" % (name, self.N, shortname))
+
+    @staticmethod
+    def _discover(datapath):
+        """(in-memory corpus or None, sorted song paths): the dataset directory holds one feature file per song,
+        .h5 in the reference (CoverAlgorithm.py:41), .npz here when no .h5 is found."""
+        if not isinstance(datapath, str):
+            return datapath, ["<memory>/song_%06d" % i for i in range(datapath.n_songs)]
+        for ext in ("h5", "npz"):
+            found = sorted(glob.glob(os.path.join(datapath, "*." + ext)))
+            if found:
+                return None, found
+        return None, []
+
+    def _matrix_path(self, similarity_type):
+        return "%s_%s_dmat" % (self.get_cacheprefix(), similarity_type)
+
+    def _open_matrix(self, similarity_type):
+        """The N x N float32 score matrix of one similarity type: file-backed under the cache prefix as in the
+        reference (:52-55) on rank 0; in memory on the other ranks of a torch.distributed job, since every rank
+        opening the same file with 'w+' would truncate it under the others."""
+        shape = (self.N, self.N)
+        if int(os.environ.get("RANK", "0")) != 0:
+            return np.zeros(shape, dtype=np.float32)
+        os.makedirs(self.cachedir, exist_ok=True)
+        return np.memmap(self._matrix_path(similarity_type), dtype=np.float32, mode="w+", shape=shape)
 
     def set_cache2dir(self, cache2dir):
         self.cache2dir = cache2dir
@@ -116,30 +122,32 @@ class CoverAlgorithm(object):
         self.cliques[feats['label']].add(i)
         return feats
 
+    def _join_clique(self, label, i):
+        self.cliques.setdefault(label, set()).add(int(i))
+
     def get_all_clique_ids(self, verbose=False):
-        """Clique membership of every song, cached in <prefix>_clique_info.txt (CoverAlgorithm.py:92-114)."""
-        filepath = "%s_clique_info.txt" % self.get_cacheprefix()
+        """Clique membership of every song (CoverAlgorithm.py:92-114): read from the "<index>,<label>" lines of
+        <prefix>_clique_info.txt when that file exists, otherwise taken from every song's feature file (base-class
+        loader, so a plugin's feature cache is not filled) and written there."""
         if self.corpus is not None:
-            for i, lab in enumerate(self.corpus.labels):
-                self.cliques.setdefault(lab, set([])).add(i)
+            for i, label in enumerate(self.corpus.labels):
+                self._join_clique(label, i)
             return
-        if not os.path.exists(filepath):
-            if not os.path.isdir(self.cachedir):
-                os.makedirs(self.cachedir)
-            with open(filepath, "w") as fout:
-                for i in range(len(self.filepaths)):
-                    feats = CoverAlgorithm.load_features(self, i)
-                    if verbose:
-                        print(i)
-                    fout.write("%i,%s\n" % (i, feats['label']))
-        else:
-            with open(filepath) as fin:
-                for line in fin.readlines():
-                    i, label = line.split(",")
-                    label = label.strip()
-                    if label not in self.cliques:
-                        self.cliques[label] = set([])
-                    self.cliques[label].add(int(i))
+        listing = self.get_cacheprefix() + "_clique_info.txt"
+        if os.path.exists(listing):
+            with open(listing) as fin:
+                for line in fin:
+                    if line.strip():
+                        i, label = line.split(",", 1)
+                        self._join_clique(label.strip(), i)
+            return
+        os.makedirs(self.cachedir, exist_ok=True)
+        with open(listing, "w") as fout:
+            for i in range(len(self.filepaths)):
+                label = CoverAlgorithm.load_features(self, i)["label"]      # joins the clique as a side effect
+                fout.write("%i,%s\n" % (i, label))
+                if verbose:
+                    print(i)
 
     def similarity(self, idxs):
         """
@@ -253,66 +261,73 @@ class CoverAlgorithm(object):
         keep = (rr < n_songs) & (cc < n_songs) & (rr >= cc)
         return np.stack([rr[keep], cc[keep]], axis=1)
 
+    def _checkpoint_path(self, idx):
+        return "%s_%s.npz" % (self.get_cacheprefix(), idx)
+
+    @staticmethod
+    def _read_checkpoint(path):
+        """(accumulated result arrays, set of finished sub-blocks) of a block checkpoint; empty when the file is
+        absent or unreadable (the reference recomputes in that case too, :262-267)."""
+        if not os.path.exists(path):
+            return {}, set()
+        try:
+            with np.load(path) as z:
+                done = set((int(i), int(j)) for i, j in z["blocks_completed"])
+                return {name[len("sim_"):]: z[name] for name in z.files if name.startswith("sim_")}, done
+        except Exception:
+            print("Error loading", path, ": recomputing")
+            return {}, set()
+
+    def _write_checkpoint(self, path, acc, done):
+        os.makedirs(self.cachedir, exist_ok=True)
+        arrays = {"sim_" + name: arr for name, arr in acc.items()}
+        arrays["blocks_completed"] = np.array(sorted(done), dtype=np.int64).reshape(-1, 2)
+        np.savez(path, **arrays)
+
     def do_batch(self, w, idx, wsub=-1):
         """
-        Compute and checkpoint block `idx` sub-block by sub-block, resuming from
-        <prefix>_<idx>.npz if it exists (CoverAlgorithm.py:249-295).
+        Block `idx` of the w x w block grid, computed in wsub x wsub sub-blocks and checkpointed after each one in
+        <prefix>_<idx>.npz (arrays "sim_<key>" + "blocks_completed"); sub-blocks the checkpoint already holds are
+        skipped, so an interrupted job resumes (CoverAlgorithm.py:249-295).  Sub-block rows are walked boustrophedon
+        (:294-295), which keeps the songs of the previous sub-block's edge in a plugin's cache.
         """
-        similarities = {}
-        blocks_completed = {}
-        fout = "{}_{}.npz".format(self.get_cacheprefix(), idx)
-        if os.path.exists(fout):
-            try:
-                with np.load(fout) as z:
-                    similarities = {k[4:]: z[k] for k in z.files if k.startswith("sim_")}
-                    blocks_completed = {(int(a), int(b)): True for a, b in z["blocks_completed"]}
-            except Exception:
-                print("Error loading", fout, ": recomputing")
-                similarities, blocks_completed = {}, {}
-        if wsub == -1:
-            wsub = w
-        k = int(w / wsub)
-        col_range = list(range(k))
-        for i in range(k):
-            for j in col_range:
-                if not (i, j) in blocks_completed:
-                    tic = time.time()
-                    self.all_feats = {}   # :282 drop cached features between sub-blocks
-                    s = self.do_batch_subbatch(w, idx, wsub, i, j)
-                    if len(similarities) == 0:
-                        similarities = s
-                    else:
-                        for key in s:
-                            similarities[key] = np.concatenate((similarities[key], s[key]))
-                    blocks_completed[(i, j)] = True
-                    if not os.path.isdir(self.cachedir):
-                        os.makedirs(self.cachedir)
-                    np.savez(fout, blocks_completed=np.array(sorted(blocks_completed), dtype=np.int64).reshape(-1, 2),
-                             **{"sim_" + key: val for key, val in similarities.items()})
-                    print("Elapsed Time Sub-Batch %i_%i_%i: %.3g" % (idx, i, j, time.time() - tic), flush=True)
-            col_range = list(reversed(col_range))   # zig-zag (:294-295)
-        return similarities
+        path = self._checkpoint_path(idx)
+        acc, done = self._read_checkpoint(path)
+        per_side = int(w / (w if wsub == -1 else wsub))
+        wsub = w if wsub == -1 else wsub
+        for i in range(per_side):
+            cols = range(per_side) if i % 2 == 0 else range(per_side - 1, -1, -1)
+            for j in cols:
+                if (i, j) in done:
+                    continue
+                tic = time.time()
+                self.all_feats = {}                       # features of the finished sub-blocks are dropped (:282)
+                part = self.do_batch_subbatch(w, idx, wsub, i, j)
+                acc = dict(part) if not acc else {name: np.concatenate((acc[name], part[name])) for name in part}
+                done.add((i, j))
+                self._write_checkpoint(path, acc, done)
+                print("Elapsed Time Sub-Batch %i_%i_%i: %.3g" % (idx, i, j, time.time() - tic), flush=True)
+        return acc
 
     def load_batches(self, fileprefix):
-        """Scatter-add every checkpointed block into Ds, both triangles (CoverAlgorithm.py:297-317)."""
-        files = glob.glob("{}*.npz".format(fileprefix))
-        for key in self.Ds.keys():
-            self.Ds[key] = np.zeros_like(self.Ds[key])
-        for f in files:
-            with np.load(f) as z:
+        """Ds rebuilt from every block checkpoint "<fileprefix>*.npz": each pair's score is added at (i, j) and at
+        (j, i) -- a diagonal pair therefore twice, as in CoverAlgorithm.py:297-317."""
+        self.Ds = {name: np.zeros_like(D) for name, D in self.Ds.items()}
+        for path in glob.glob(fileprefix + "*.npz"):
+            with np.load(path) as z:
                 if "sim_idxs" not in z.files:
                     continue
-                idxs = z["sim_idxs"]
-                I, J = idxs[:, 0], idxs[:, 1]
-                for key in self.Ds.keys():
-                    self.Ds[key][I, J] += z["sim_" + key]
-                    self.Ds[key][J, I] += z["sim_" + key]
+                rows, cols = z["sim_idxs"][:, 0], z["sim_idxs"][:, 1]
+                for name, D in self.Ds.items():
+                    scores = z["sim_" + name]
+                    for a, b in ((rows, cols), (cols, rows)):
+                        D[a, b] = D[a, b] + scores
         self.get_all_clique_ids()
 
     def cleanup_memmap(self):
         """Remove the memmap files behind Ds (the reference's rmtree on a file never succeeds, :319-328)."""
         for s in list(getattr(self, "Ds", {})):
-            path = '%s_%s_dmat' % (self.get_cacheprefix(), s)
+            path = self._matrix_path(s)
             try:
                 if os.path.exists(path):
                     os.remove(path)
@@ -394,23 +409,21 @@ class CoverAlgorithm(object):
         if verbose:
             print("%s %s STATS\n-------------------------\nMR = %.3g\nMRR = %.3g\nMDR = %.3g\nMAP = %.3g"
                   % (self.name, similarity_type, MR, MRR, MDR, MAP))
-        tops = np.zeros(len(topsidx))
-        for i in range(len(tops)):
-            tops[i] = np.sum(ranks <= topsidx[i])
-            if verbose:
-                print("Top-%i: %i" % (topsidx[i], tops[i]))
+        tops = np.array([np.sum(ranks <= t) for t in topsidx], dtype=np.float64)
+        if verbose:
+            for t, n in zip(topsidx, tops):
+                print("Top-%i: %i" % (t, n))
         if write_csv:
-            resultsfile = "results_%s.csv" % self.shortname       # :404-417, same columns
-            if not os.path.exists(resultsfile):
-                with open(resultsfile, "w") as fout:
-                    fout.write("name, MR, MRR, MDR, MAP")
-                    for t in topsidx:
-                        fout.write(",Top-%i" % t)
-                    fout.write("\n")
-            with open(resultsfile, "a") as fout:
-                fout.write("%s_%s," % (self.name, similarity_type))
-                fout.write("%.3g, %.3g, %.3g, %.3g" % (MR, MRR, MDR, MAP))
-                for t in tops:
-                    fout.write(", %.3g" % t)
-                fout.write("\n")
+            self._append_results_row(similarity_type, topsidx, (MR, MRR, MDR, MAP), tops)
         return (MR, MRR, MDR, MAP, tops)
+
+    def _append_results_row(self, similarity_type, topsidx, stats, tops):
+        """One line per (algorithm, similarity type) in results_<shortname>.csv, header written with the first line;
+        columns and number format of CoverAlgorithm.py:404-417."""
+        path = "results_%s.csv" % self.shortname
+        lines = []
+        if not os.path.exists(path):
+            lines.append("name, MR, MRR, MDR, MAP" + "".join(",Top-%i" % t for t in topsidx))
+        lines.append("%s_%s," % (self.name, similarity_type) + ", ".join("%.3g" % v for v in list(stats) + list(tops)))
+        with open(path, "a") as fout:
+            fout.write("\n".join(lines) + "\n")

@@ -108,3 +108,34 @@ def test_subbatch_indexing_matches_reference_rule(tmp_path):
     n_calls = len(seen)
     out = alg.do_batch(4, 2, 2)
     assert len(seen) == n_calls and len(out["idxs"]) == 10 and os.path.exists(str(tmp_path / "cache" / "Probe_p_2.npz"))
+
+
+def test_checkpoints_rebuild_matrix_and_clique_listing(tmp_path):
+    """load_batches adds every checkpointed pair at (i, j) and (j, i) (CoverAlgorithm.py:297-317); the clique listing
+    is written once and read back (":92-114")."""
+    class Probe(CoverAlgorithm):
+        def similarity(self, idxs):
+            idxs = np.asarray(idxs)
+            return {"main": (10.0 * idxs[:, 0] + idxs[:, 1]).astype(np.float64)}
+
+    data = tmp_path / "data"
+    data.mkdir()
+    for i in range(8):
+        np.savez(str(data / ("s%02d.npz" % i)), label=np.array("c%d" % (i // 2)), hpcp=np.zeros((4, 12)))
+    alg = Probe("Probe", datapath=str(data), shortname="q", cachedir=str(tmp_path / "cache"), do_memmaps=True)
+    assert alg.N == 8 and isinstance(alg.Ds["main"], np.memmap)
+    for idx in range(3):                                   # the three blocks of the 2 x 2 lower-triangular block grid
+        alg.do_batch(4, idx, 2)
+    alg.load_batches(alg.get_cacheprefix() + "_")
+    D = alg.Ds["main"]
+    i, j = np.tril_indices(8, -1)
+    assert np.array_equal(D[i, j], 10.0 * i + j) and np.array_equal(D[j, i], 10.0 * i + j)
+    assert np.array_equal(np.diag(D), 2 * 11.0 * np.arange(8))          # a diagonal pair lands twice
+    assert alg.cliques == {"c%d" % c: {2 * c, 2 * c + 1} for c in range(4)}
+    listing = open(alg.get_cacheprefix() + "_clique_info.txt").read().splitlines()
+    assert listing[3] == "3,c1" and len(listing) == 8
+    again = Probe("Probe", datapath=str(data), shortname="q", cachedir=str(tmp_path / "cache"), do_memmaps=False)
+    again.get_all_clique_ids()
+    assert again.cliques == alg.cliques
+    alg.cleanup_memmap()
+    assert not os.path.exists(alg.get_cacheprefix() + "_main_dmat")
