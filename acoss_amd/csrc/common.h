@@ -33,6 +33,14 @@ inline int launch_check(const char *name)
 }
 
 __host__ __device__ inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// The strip kernels address a pair's result matrix with 32-bit byte offsets (buffer stores: wave-uniform row offset + lane
+// offset, {crp,strip32}_*.hip), rows of the last, partly filled step included.  Host-side bound on the matrix a launch may
+// be given: rows padded by one 64-row step, pitches of up to max_ny + 256 elements (acoss_plan_pairs pads to pitch_align).
+inline bool strip_offsets_fit(int max_nx, int max_ny, int cell_bytes)
+{
+    return (int64_t)cell_bytes * ((int64_t)max_nx + 64) * ((int64_t)max_ny + 256) < 0x7fffffffLL;
+}
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // CRPUtils.py:186-193 neighbour count (host side; kappa*ncols rounded half-to-even like np.round)

@@ -1001,6 +1001,7 @@ int acoss_csm_batch_f32(const float *feats, const float *norms, int d, const aco
     return launch_csm<float>(feats, norms, d, descs, K, max_nx, max_ny, csm, (hipStream_t)stream);
 }
 
+#ifdef ACOSS_PROBES      // python -m acoss_amd.build --probes: the MODE != 0 instantiations exist only in that build
 // development probe (not part of the public ABI): select_rows in a probe MODE
 int acoss_dev_select_probe(int mode, const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx,
                            int max_ny, double kappa, void *work, void *stream)
@@ -1046,6 +1047,7 @@ int acoss_dev_csm_probe(int mode, const double *feats, const double *norms, cons
     else hipLaunchKernelGGL((csm_kernel<double, 12, 0>), dim3(blocks), dim3(256), 0, st, feats, norms, descs, tm, tn, csm);
     return launch_check("csm_kernel probe");
 }
+#endif  // ACOSS_PROBES
 
 int acoss_sliding_batch_f64(const double *csm, const acoss_pair_desc *descs, int K, int win,
                             int max_nx, int max_ny, double *S, void *stream)

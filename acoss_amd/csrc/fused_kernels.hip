@@ -459,6 +459,9 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
     const int o_rows = CSM_LAYOUT ? ds.nx : M;
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(out) + OB * o_off, 0, (int)(OB * (int64_t)o_rows * o_pitch), BUFFER_RSRC_WORD3);
+    // 32-bit offsets below: the launchers refuse shapes beyond strip_offsets_fit(); a descriptor whose pitch breaks that
+    // bound all the same gets no stores at all rather than stores at wrapped offsets
+    if ((int64_t)OB * ((int64_t)o_rows + 2 * STRIP_ROWS) * o_pitch > 0x7fffffffLL) return;
     const int orow0 = (wave * ROWS_PER_WAVE - HALO) * o_pitch + j0;   // element index of (first row of the wave, strip column 0)
     static_assert(!PLANAR || ((TN + ROWS_PER_WAVE <= CRP_CT) && !SQRT_OUT && !CSM_LAYOUT), "planar output: diagonal-run form only");
 
@@ -783,6 +786,10 @@ static int launch_crp(const T *xp, const T *feats, const T *norms, int d, const 
     const int tm = ceil_div(max_nx - win + 1, TM), tn = ceil_div(max_ny - win + 1, TN);
     const int64_t blocks = (int64_t)K * tm * tn;
     if (blocks > 0x7fffffffLL) { set_error("crp_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if (!strip_offsets_fit(max_nx, max_ny, 8)) {
+        set_error("crp_batch: a pair's result matrix must stay below 2 GiB (32-bit store offsets)");
+        return ACOSS_ENOTSUP;
+    }
     // flags: bit 0 = sqrt, bit 1 = all-VALU tile kernel, bit 2 = matrix-core tile kernel;
     // default for float64 and the window of the paper (m = 9): the persistent strip kernel
     if constexpr (sizeof(T) == 8) {
@@ -804,6 +811,7 @@ using namespace acoss;
 
 extern "C" {
 
+#ifdef ACOSS_PROBES      // python -m acoss_amd.build --probes
 // development probe (not part of the public ABI): strip kernel in a probe MODE
 int acoss_dev_crp_probe(int mode, const double *xp, const double *feats, const double *norms,
                         const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *out, void *stream)
@@ -819,6 +827,7 @@ int acoss_dev_crp_probe(int mode, const double *xp, const double *feats, const d
     else hipLaunchKernelGGL((crp_strip_kernel<12, 9, false, 0>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     return launch_check("crp_strip probe");
 }
+#endif  // ACOSS_PROBES
 
 int64_t acoss_xpack_elems(int K, int max_nx)
 {
@@ -856,6 +865,10 @@ int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const doubl
         return ACOSS_EINVAL;
     }
     if (d != 12 && d != 13) { set_error("csm_strip_batch: d must be 12 or 13"); return ACOSS_ENOTSUP; }
+    if (!strip_offsets_fit(max_nx, max_ny, 8)) {
+        set_error("csm_strip_batch: a pair's matrix must stay below 2 GiB (32-bit store offsets)");
+        return ACOSS_ENOTSUP;
+    }
     if (K == 0) return ACOSS_OK;
     const int strips = ceil_div(max_ny, CRP_CT);
     const unsigned blocks = (unsigned)((int64_t)K * strips);
@@ -884,7 +897,10 @@ int acoss_crp_planar_batch_f64(const double *xp, const double *feats, const doub
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
-    if ((int64_t)K * ceil_div(max_ny - win + 1, strip_tn(win)) > 0x7fffffffLL) { set_error("crp_planar_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if ((int64_t)K * ceil_div(max_ny - win + 1, strip_tn(win)) > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) {
+        set_error("crp_planar_batch: batch too large");
+        return ACOSS_ENOTSUP;
+    }
     if (d == 12) launch_crp_strip_planar<12>(xp, max_nx, feats, norms, descs, K, max_ny, planes, (hipStream_t)stream);
     else launch_crp_strip_planar<13>(xp, max_nx, feats, norms, descs, K, max_ny, planes, (hipStream_t)stream);
     return launch_check("crp_strip_kernel<planar>");

@@ -421,6 +421,7 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         }
         return launch_combine_bits(descs, K, win, mutual, w, bits, st);
     }
+#ifdef ACOSS_PROBES
     if (probe == 1) {
         hipLaunchKernelGGL(select_rows_planar_kernel<1>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
         return launch_check("select_rows_planar probe");
@@ -435,6 +436,9 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         hipLaunchKernelGGL(select_cols_planar_kernel<1>, dim3((unsigned)((int64_t)K * cb)), dim3(512), lds, st, planes, descs, win, kv, mode, w, cb);
         return launch_check("select_cols_planar probe");
     }
+#else
+    if (probe != 0) { set_error("mask_bits_planar: probes need a --probes build"); return ACOSS_ENOTSUP; }
+#endif
     if (probe == 0 || probe == 2) {
         hipLaunchKernelGGL(select_rows_planar_kernel<0>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
         int rc = launch_check("select_rows_planar_kernel");
@@ -501,6 +505,7 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
                       (hipStream_t)stream, band);
 }
 
+#ifdef ACOSS_PROBES
 // development probe (not part of the public ABI): 1 = row loads only, 2 = row selection kernel alone,
 // 11 = column loads only, 12 = column selection kernel alone
 int acoss_dev_planar_probe(int probe, const uint32_t *planes, const double *feats, const double *norms, int d,
@@ -510,5 +515,6 @@ int acoss_dev_planar_probe(int probe, const uint32_t *planes, const double *feat
     return run_planar(probe, planes, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, 1, nullptr, work, work_bytes,
                       (hipStream_t)stream);
 }
+#endif  // ACOSS_PROBES
 
 }  // extern "C"

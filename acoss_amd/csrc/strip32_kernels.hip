@@ -86,6 +86,7 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
 
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(out) + 4 * ds.crp_off, 0, (int)(4 * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
+    if ((int64_t)4 * ((int64_t)M + 2 * S32_ROWS) * ds.crp_pitch > 0x7fffffffLL) return;      // 32-bit offsets, see strip_offsets_fit()
     const int orow0 = (wave * S32_RPW - S32_HALO) * ds.crp_pitch + j0;
 
     float4 xn1 = make_float4(0.f, 0.f, 0.f, 0.f), xn2 = xn1;
@@ -198,11 +199,13 @@ extern "C" int acoss_crp_planar32_batch(const float *xp, const float *feats, con
     }
     if (K == 0) return ACOSS_OK;
     const int strips = ceil_div(max_ny - win + 1, S32_TN);
-    if ((int64_t)K * strips > 0x7fffffffLL) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if ((int64_t)K * strips > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
     const unsigned blocks = (unsigned)((int64_t)K * strips);
     hipStream_t st = (hipStream_t)stream;
-    if (getenv("ACOSS_STRIP32_NOSTORE")) hipLaunchKernelGGL((crp_strip32_kernel<12, 1>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
-    else if (d == 12) hipLaunchKernelGGL(crp_strip32_kernel<12>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
+#ifdef ACOSS_PROBES
+    if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_strip32_kernel<12, 1>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out); return launch_check("crp_strip32_kernel probe"); }
+#endif
+    if (d == 12) hipLaunchKernelGGL(crp_strip32_kernel<12>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else hipLaunchKernelGGL(crp_strip32_kernel<13>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     return launch_check("crp_strip32_kernel");
 }

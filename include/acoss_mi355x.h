@@ -177,7 +177,12 @@ int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float 
                                const acoss_pair_desc *descs, int K, int max_nx, int max_ny, float *csm,
                                void *stream);
 /* float64 get_csm through the persistent matrix-core strip kernel (same output as acoss_csm_batch_f64
- * up to the rounding of one FMA-chain order; d in {12, 13}). */
+ * up to the rounding of one FMA-chain order; d in {12, 13}).
+ * Size limit of the strip kernels (this one, acoss_crp_batch_f64 with win == 9, acoss_crp_planar_batch_f64,
+ * acoss_crp_planar32_batch): they address ONE pair's result matrix with 32-bit byte offsets, so
+ * cell_bytes * (max_nx + 64) * (max_ny + 256) must stay below 2^31 (cell_bytes 8, or 4 for the planar forms) --
+ * about 16000 x 16000 frames for float64 -- and the descriptors' pitches at most max_ny + 256.  Larger shapes
+ * return ACOSS_ENOTSUP (use acoss_csm_batch + acoss_sliding_batch, which index with 64 bits). */
 int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm,
                               void *stream);

@@ -1,4 +1,5 @@
-"""Phase shares of the band kernel (STAMP build: ACOSS_BAND_STAMP=1): python tools/band_stamps.py [pairs]"""
+"""Phase shares of the band kernel (needs `python -m acoss_amd.build --probes`; sets ACOSS_BAND_STAMP=1):
+python tools/band_stamps.py [pairs]"""
 import ctypes
 import os
 import sys
@@ -20,6 +21,8 @@ engine.oti(corpus, batch)
 band = engine.planar32_band(corpus, batch, fused=True)
 bits, work = engine.mask_bits_fused(corpus, batch, 0.095, band=band)
 lib = ctypes.CDLL(_lib.LIB_PATH)
+if not hasattr(lib, "acoss_dev_band_stamps"):
+    raise SystemExit("development probes are not in this build: python -m acoss_amd.build --probes")
 out = (ctypes.c_ulonglong * 12)()
 lib.acoss_dev_band_stamps(out, 12)          # reset
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

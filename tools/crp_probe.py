@@ -13,6 +13,8 @@ engine.oti(corpus, batch)
 xp = engine.pack_x(corpus, batch)
 T = torch.empty(batch.total_crp, dtype=torch.float64, device=corpus.device)
 lib = _lib.load()
+if not hasattr(lib, "acoss_dev_crp_probe"):
+    raise SystemExit("development probes are not in this build: python -m acoss_amd.build --probes")
 fn = lib.acoss_dev_crp_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 4 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2

@@ -12,6 +12,8 @@ batch = engine.PairBatch(corpus.frame_off, allp[np.arange(K) % len(allp)], 9, co
 engine.oti(corpus, batch)
 C = torch.empty(batch.total_csm, dtype=torch.float64, device=corpus.device)
 lib = _lib.load()
+if not hasattr(lib, "acoss_dev_csm_probe"):
+    raise SystemExit("development probes are not in this build: python -m acoss_amd.build --probes")
 fn = lib.acoss_dev_csm_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int] + [ctypes.c_void_p] * 3 + [ctypes.c_int] * 3 + [ctypes.c_void_p] * 2

@@ -14,6 +14,8 @@ xp = engine.pack_x(corpus, batch)
 T = engine.crp(corpus, batch, xp)
 lib = _lib.load()
 work = torch.empty(int(lib.acoss_binarize_work_bytes(K, 1000, 1000, 9)), dtype=torch.uint8, device=corpus.device)
+if not hasattr(lib, "acoss_dev_select_probe"):
+    raise SystemExit("development probes are not in this build: python -m acoss_amd.build --probes")
 fn = lib.acoss_dev_select_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_double, ctypes.c_void_p, ctypes.c_void_p]

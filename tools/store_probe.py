@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import _lib, engine
 engine.require_gpu()
 lib = _lib.load()
+if not hasattr(lib, "acoss_dev_store_probe"):
+    raise SystemExit("development probes are not in this build: python -m acoss_amd.build --probes")
 fn = lib.acoss_dev_store_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p]
