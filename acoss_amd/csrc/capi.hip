@@ -78,6 +78,24 @@ static float align_host(unsigned char *S, float *D, int rows, int cols, int d_ro
 
 using namespace acoss;
 
+namespace acoss {
+
+int device_cus()
+{
+    static thread_local int cached_dev = -1, cached_cus = 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return 256; }
+    if (dev != cached_dev) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 1) { (void)hipGetLastError(); n = 256; }
+        cached_dev = dev;
+        cached_cus = n;
+    }
+    return cached_cus;
+}
+
+}  // namespace acoss
+
 extern "C" {
 
 int acoss_abi_version(void) { return ACOSS_ABI_VERSION; }

@@ -41,6 +41,9 @@ inline bool strip_offsets_fit(int max_nx, int max_ny, int cell_bytes)
 {
     return (int64_t)cell_bytes * ((int64_t)max_nx + 64) * ((int64_t)max_ny + 256) < 0x7fffffffLL;
 }
+// Compute units of the current device (256 on MI355X): the grid unit of the persistent kernels.  capi.hip.
+int device_cus();
+
 __host__ __device__ inline int64_t ceil_div64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 // CRPUtils.py:186-193 neighbour count (host side; kappa*ncols rounded half-to-even like np.round)

@@ -68,7 +68,7 @@ __global__ __launch_bounds__(64) void select_fix_side_kernel(const double *__res
 }
 
 // ---- rows ------------------------------------------------------------------------------------------------
-constexpr int PL_ROWS_PER_WAVE = 8;
+constexpr int PL_ROWS_PER_WAVE = 16;
 
 // MODE (development probes): 1 = loads only
 template <int MODE = 0, int E = 16>
@@ -98,6 +98,15 @@ __global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kerne
     for (int i = r0; i < r1; i++) {
         const uint32_t *row = Thi + ds.crp_off + (int64_t)i * ds.crp_pitch;
         unsigned h[E];
+        if constexpr (MODE == 3) {
+            // probe: no loads, keys made up in registers (a smooth ramp + hashed low bits, so that the window prediction
+            // works as on real rows): the selection alone at full occupancy
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const unsigned q = (unsigned)(e * 64 + lane);
+                h[e] = 0xbf000000u + (((q * 2654435761u) ^ ((unsigned)i * 40503u)) >> 10) + ((q * 2246822519u) >> 12);
+            }
+        } else
         if (wide) {
             // wave-uniform row pointer + one lane offset + immediates: 256 contiguous bytes per load instruction
 #pragma unroll
@@ -112,6 +121,7 @@ __global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kerne
 #pragma unroll
             for (int e = 0; e < E; e++) h[e] = row[(unsigned)min(e * 64 + lc, N - 1)];
         }
+        if constexpr (E == 16) planar_pad_keys<E>(h, N, lane, wide);
         if constexpr (MODE == 1) {
             unsigned acc = 0;
 #pragma unroll
@@ -121,9 +131,12 @@ __global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kerne
         }
         SelectResult res;
         if (!planar_trivial(k, N, res)) {
-            if constexpr (E == 16) res = wave_select_hist256_u32(h, N, k, hist, lane, warm);
-            else res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
-            band_resolve<E>(h, N, w.band, p, lane, res);
+            if constexpr (E == 16) {
+                res = wave_select_hist256_u32(h, N, k, hist, lane, warm, w.band != nullptr ? w.band + 2 * p : nullptr);
+            } else {
+                res = wave_select_hist_u32<E>(h, N, k, hist, lane, warm);
+                band_resolve<E>(h, N, w.band, p, lane, res);
+            }
         }
         if constexpr (E == 16) {
             if (w.band != nullptr && res.cut == SELECT_UNRESOLVED) side_hand_over<E>(h, w, p, 0, i, N, res, lane);
@@ -209,6 +222,8 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     const int lane = threadIdx.x & 63;
     const int ja = j0 + 2 * wave;
     if (ja >= N) return;
+    planar_pad_keys<16>(ha, M, lane, M > 15 * 64);
+    planar_pad_keys<16>(hb, M, lane, M > 15 * 64);
     if constexpr (MODE == 1) {
         unsigned acc = 0;
 #pragma unroll
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
         return;
     }
     unsigned *hist = pcolbuf + (2 * wave) * PL_LDC;      // the wave's two slots: 2 * PL_LDC words >= HIST_WORDS, 16-byte aligned
-    hist_clear(hist, lane);
+    hist256_clear(hist, lane);
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<16>(M, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
@@ -226,8 +241,7 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
         else if (!planar_trivial(k, M, res)) {
-            res = wave_select_hist256_u32(h, M, k, hist, lane, warm);
-            band_resolve<16>(h, M, w.band, p, lane, res);
+            res = wave_select_hist256_u32(h, M, k, hist, lane, warm, w.band != nullptr ? w.band + 2 * p : nullptr);
         }
         if (w.band != nullptr && res.cut == SELECT_UNRESOLVED) side_hand_over<16>(h, w, p, 1, j, M, res, lane);
         if (lane == 0) {
@@ -422,6 +436,10 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
         return launch_combine_bits(descs, K, win, mutual, w, bits, st);
     }
 #ifdef ACOSS_PROBES
+    if (probe == 3) {
+        hipLaunchKernelGGL(select_rows_planar_kernel<3>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
+        return launch_check("select_rows_planar probe");
+    }
     if (probe == 1) {
         hipLaunchKernelGGL(select_rows_planar_kernel<1>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, planes, descs, win, kv, mode, w, rb);
         return launch_check("select_rows_planar probe");

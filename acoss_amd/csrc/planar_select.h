@@ -19,6 +19,20 @@ __device__ inline void planar_put_lane_u64(unsigned &lo, unsigned &hi, uint64_t 
         : "s"((unsigned)m), "s"((unsigned)(m >> 32)), "n"(e));
 }
 
+// four masks into lanes e .. e+3 (one wait state for the four VALU-written SGPR pairs instead of one each)
+__device__ inline void planar_put_lanes4_u64(unsigned &lo, unsigned &hi, uint64_t m0, uint64_t m1, uint64_t m2, uint64_t m3, int e)
+{
+    asm("s_nop 1\n\t"
+        "v_writelane_b32 %0, %2, %10\n\tv_writelane_b32 %1, %3, %10\n\t"
+        "v_writelane_b32 %0, %4, %11\n\tv_writelane_b32 %1, %5, %11\n\t"
+        "v_writelane_b32 %0, %6, %12\n\tv_writelane_b32 %1, %7, %12\n\t"
+        "v_writelane_b32 %0, %8, %13\n\tv_writelane_b32 %1, %9, %13"
+        : "+v"(lo), "+v"(hi)
+        : "s"((unsigned)m0), "s"((unsigned)(m0 >> 32)), "s"((unsigned)m1), "s"((unsigned)(m1 >> 32)),
+          "s"((unsigned)m2), "s"((unsigned)(m2 >> 32)), "s"((unsigned)m3), "s"((unsigned)(m3 >> 32)),
+          "n"(e), "n"(e + 1), "n"(e + 2), "n"(e + 3));
+}
+
 // lane e (< E) = lane mask of "position e*64 + lane exists"
 template <int E>
 __device__ inline uint64_t planar_slot_valid(int n, int lane)
@@ -29,14 +43,37 @@ __device__ inline uint64_t planar_slot_valid(int n, int lane)
     return ((uint64_t)hi << 32) | lo;
 }
 
+// Padding convention of the 16-keys-per-lane selection (wave_select_hist256_u32): positions >= n hold PLANAR_PAD, a key
+// no finite value maps to (the NaN pattern) and that therefore sorts above every real key -- it is never below a
+// window, never inside an error band, never selected, and lands in a bin of its own above the real keys.  The counting
+// loops then need no validity mask.  (The 32-keys-per-lane selection repeats a real element there and masks instead.)
+constexpr unsigned PLANAR_PAD = 0xffffffffu;
+
+// h[e] = PLANAR_PAD where position e*64 + lane >= n.  last_only: the caller knows that only slot E-1 can run past n.
+template <int E>
+__device__ inline void planar_pad_keys(unsigned (&h)[E], int n, int lane, bool last_only)
+{
+    if (last_only) {
+        h[E - 1] = (E - 1) * 64 + lane < n ? h[E - 1] : PLANAR_PAD;
+        return;
+    }
+#pragma unroll
+    for (int e = 0; e < E; e++) h[e] = e * 64 + lane < n ? h[e] : PLANAR_PAD;
+}
+
 // word e of out = lanes whose element e is selected (high word <= the threshold's), positions e*64 + lane
 template <int E>
 __device__ inline void planar_emit_bits(const unsigned (&h)[E], unsigned thr_hi, uint64_t valid, uint64_t *out, int lane,
                                         int64_t stride = 1)
 {
     unsigned lo = 0, hi = 0;
+    static_assert(E % 4 == 0, "ballots are moved into their lanes four at a time");
 #pragma unroll
-    for (int e = 0; e < E; e++) planar_put_lane_u64(lo, hi, __ballot(h[e] <= thr_hi), e);
+    for (int e = 0; e < E; e += 4) {
+        const uint64_t m0 = __ballot(h[e] <= thr_hi), m1 = __ballot(h[e + 1] <= thr_hi);
+        const uint64_t m2 = __ballot(h[e + 2] <= thr_hi), m3 = __ballot(h[e + 3] <= thr_hi);
+        planar_put_lanes4_u64(lo, hi, m0, m1, m2, m3, e);
+    }
     if (lane < E) out[lane * stride] = (((uint64_t)hi << 32) | lo) & valid;
 }
 
@@ -169,7 +206,7 @@ __device__ inline SelectResult wave_select_hist_u32(const unsigned (&h)[E], int 
 // 4 x 16 bytes at a 64-byte lane stride (4-way bank conflicts on the reads and on the clears) and needs a second, dependent
 // LDS read for its second level.  Bins are 4x wider for the same window; the 1-3 keys of the winning bin are ranked by
 // v_readlane as before.  hist: 256 + 64 words, zero on entry and on return.  warm.shift is in this function's own bins
-// (HIST256_SHIFT0 for float64 high words, + 3 for float32 keys).
+// (HIST256_SHIFT0 for float64 high words, + 3 for float32 keys).  h: positions >= n hold PLANAR_PAD (planar_pad_keys).
 constexpr int HIST256_LOG2 = 8, HIST256_BINS = 1 << HIST256_LOG2;
 constexpr int HIST256_SHIFT0 = HIST_WARM_SHIFT0 + 2, HIST256_SHIFT_MAX = HIST_WARM_SHIFT_MAX + 5;
 
@@ -179,7 +216,27 @@ __device__ inline void hist256_clear(unsigned *hist, int lane)
     hist[HIST256_BINS + lane] = 0;
 }
 
-__device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], int n, int k, unsigned *hist, int lane, HistWarm &warm)
+__device__ inline void band_limits(unsigned th, const float *pair_band, unsigned &lo, unsigned &hi);
+template <int E>
+__device__ inline bool band_crowded(const unsigned (&h)[E], unsigned lo, unsigned hi);
+
+// unsigned saturating subtraction (v_sub_u32 with the clamp bit): max(a, b) - b in one instruction; b wave-uniform
+__device__ inline unsigned sat_sub_u32(unsigned a, unsigned b_uniform)
+{
+    unsigned d;
+    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(b_uniform));
+    return d;
+}
+
+// Instruction budget: at eight waves per SIMD these kernels are bound by instruction issue, not by latency (the
+// selection alone on made-up keys takes as long as the loads alone, tools/planar_probe.py), so every per-key
+// instruction counts sixteen times per row.  Per key there are: the bin (saturating subtract, shift, min), the LDS
+// add, and compare + select for the candidates.  There is no count of the keys below the window: bin 0 takes them (the
+// subtraction saturates), so ranks stay global in every pass; and the error band of approximate keys (pair_band != null:
+// band_limits) is checked against the one to three candidates of the winning bin whenever it lies inside that bin --
+// against all keys only when it reaches over the bin's edge.
+__device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], int n, int k, unsigned *hist, int lane, HistWarm &warm,
+                                                       const float *pair_band = nullptr)
 {
     constexpr int E = 16;
     SelectResult res;
@@ -188,84 +245,79 @@ __device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], 
     unsigned bin[E];
     enum { PREDICTED, FULL, REFINE };
     int kind = warm.hi != 0 ? PREDICTED : FULL;
-    unsigned lo = 0;
+    unsigned lo0 = 0;                       // bin b >= 1 holds the keys lo0 + (b << shift) ... ; bin 0 everything below bin 1
     int shift = warm.shift;
     if (kind == PREDICTED) {
-        const unsigned half = (unsigned)(HIST256_BINS / 2) << shift;
-        lo = max(warm.hi, half) - half;
+        const unsigned back = (unsigned)(HIST256_BINS / 2 + 1) << shift;      // the predicted key sits in the middle of bins 1 .. 255
+        lo0 = max(warm.hi, back) - back;
     }
     int r = 0, cstar = 0;
-    unsigned ch = 0;
+    unsigned ch = 0, bstar = 0;
     uint64_t any = 0;
     for (;;) {
-        int below = 0;
         if (kind == FULL) {
             unsigned mn = 0xffffffffu, mx = 0u;
 #pragma unroll
             for (int e = 0; e < E; e++) {
                 mn = min(mn, h[e]);
-                mx = max(mx, h[e]);
+                mx = max(mx, h[e] == PLANAR_PAD ? 0u : h[e]);
             }
             mn = wave_umin(mn);
             mx = wave_umax(mx);
-            lo = mn;
+            lo0 = mn;                       // nothing lies below: bin 0 is an ordinary bin in this pass
             shift = max(0, 32 - (int)__clz(mx - mn) - HIST256_LOG2);
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; e++) below += __popcll(__ballot((h[e] < lo) & (e * 64 + lane < n)));
         }
+        lo0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lo0);
         const unsigned spill = (unsigned)(HIST256_BINS + lane);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            unsigned b = min((h[e] - lo) >> shift, spill);
+            unsigned b = min(sat_sub_u32(h[e], lo0) >> shift, spill);      // above the window or padding: a spill word
             asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
-            b = e * 64 + lane < n ? b : spill;
             bin[e] = b;
             atomicAdd(&hist[b], 1u);
         }
-        const int kk = k - below;
         const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[lane];
         const int tot = (int)(c4.x + c4.y + c4.z + c4.w);
         const int incl = wave_scan<OpAdd>(tot, 0);
         hist256_clear(hist, lane);
-        const uint64_t m1 = __ballot((incl - tot < kk) & (kk <= incl));
-        if (m1 == 0) {
-            if (kind != PREDICTED) return res;
+        const uint64_t m1 = __ballot((incl - tot < k) & (k <= incl));
+        int ls = 0, ts = 0;
+        if (m1 != 0) {
+            ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
+            r = k - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
+            const int c0 = __builtin_amdgcn_readlane((int)c4.x, ls), c1 = __builtin_amdgcn_readlane((int)c4.y, ls);
+            const int c2 = __builtin_amdgcn_readlane((int)c4.z, ls), c3 = __builtin_amdgcn_readlane((int)c4.w, ls);
+            cstar = c0;
+            if (r > c0) {
+                r -= c0; ts = 1; cstar = c1;
+                if (r > c1) {
+                    r -= c1; ts = 2; cstar = c2;
+                    if (r > c2) { r -= c2; ts = 3; cstar = c3; }
+                }
+            }
+        }
+        bstar = (unsigned)(4 * ls + ts);
+        if (m1 == 0 || (kind == PREDICTED && bstar == 0)) {
+            if (kind != PREDICTED) return res;      // k outside 1..n: cannot happen
+            // the k-th smallest lies outside the predicted window: widen it for the rows to come, bin the full range now
             warm.shift = min(warm.shift + 1, HIST256_SHIFT_MAX);
             kind = FULL;
             continue;
         }
-        const int ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
-        r = kk - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
-        const int c0 = __builtin_amdgcn_readlane((int)c4.x, ls), c1 = __builtin_amdgcn_readlane((int)c4.y, ls);
-        const int c2 = __builtin_amdgcn_readlane((int)c4.z, ls), c3 = __builtin_amdgcn_readlane((int)c4.w, ls);
-        int ts = 0;
-        cstar = c0;
-        if (r > c0) {
-            r -= c0; ts = 1; cstar = c1;
-            if (r > c1) {
-                r -= c1; ts = 2; cstar = c2;
-                if (r > c2) { r -= c2; ts = 3; cstar = c3; }
-            }
-        }
-        const unsigned bstar = (unsigned)(4 * ls + ts);
-        uint64_t dup = 0;
-        any = 0;
+        // candidates: the keys of bin bstar, one per lane (keys are never 0: their sign bit is set)
+        ch = 0;
 #pragma unroll
-        for (int e = 0; e < E; e++) {
-            const bool in = bin[e] == bstar;
-            const uint64_t m = __ballot(in);
-            dup |= any & m;
-            any |= m;
-            ch = in ? h[e] : ch;
-        }
-        if (dup == 0) break;
+        for (int e = 0; e < E; e++) ch = bin[e] == bstar ? h[e] : ch;
+        any = __ballot(ch != 0);
+        if (__popcll(any) == cstar) break;          // no lane holds two of them
         if (shift == 0) {                   // equal high words in one lane: exact values needed, fix-up pass
-            res.thr_key = (uint64_t)(lo + bstar) << 32;       // (tells it which high word the ties share)
+            res.thr_key = (uint64_t)(lo0 + bstar) << 32;       // (tells it which high word the ties share)
             return res;
         }
-        lo += bstar << shift;
-        shift = max(shift - HIST256_LOG2, 0);
+        // bin bstar again, 128 times finer (bins 1 .. 128; bin 0 keeps everything below it, so k stays the rank)
+        const int fine = max(shift - (HIST256_LOG2 - 1), 0);
+        lo0 = lo0 + (bstar << shift) - (1u << fine);
+        shift = fine;
         kind = REFINE;
     }
     const bool mine = (any >> lane) & 1;
@@ -283,11 +335,21 @@ __device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], 
     if (win == 0) return res;
     const int wl = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)win) - 1);
     const unsigned th = (unsigned)__builtin_amdgcn_readlane((int)ch, wl);
-    if (__builtin_amdgcn_readlane(equal, wl) > 1) {                 // shared high word: exact values decide, fix-up pass
-        res.thr_key = (uint64_t)th << 32;
-        return res;
+    res.thr_key = (uint64_t)th << 32;
+    if (__builtin_amdgcn_readlane(equal, wl) > 1) return res;       // shared high word: exact values decide, fix-up pass
+    if (pair_band != nullptr) {
+        // approximate keys: the result stands only if the winner is alone in its error band
+        unsigned blo, bhi;
+        band_limits(th, pair_band, blo, bhi);
+        const unsigned bin_lo = lo0 + (bstar << shift), bin_hi = bin_lo + ((1u << shift) - 1u);
+        bool crowded;
+        if (blo >= bin_lo && bhi <= bin_hi && !(kind != FULL && bstar == 0))
+            crowded = cstar > 1 && __popcll(__ballot(mine & ((ch - blo) <= (bhi - blo)))) > 1;
+        else
+            crowded = band_crowded<E>(h, blo, bhi);
+        if (crowded) return res;
     }
-    res.thr_key = ((uint64_t)th << 32) | 0xffffffffull;
+    res.thr_key |= 0xffffffffull;
     res.cut = 0x7fffffff;
     warm.hi = th;
     return res;
@@ -318,6 +380,18 @@ __device__ inline int band_count(const unsigned (&h)[E], unsigned lo, unsigned h
     return c;
 }
 
+// more than one of the wave's keys inside [lo, hi]? (wave-uniform; counted per lane, two ballots at the end)
+template <int E>
+__device__ inline bool band_crowded(const unsigned (&h)[E], unsigned lo, unsigned hi)
+{
+    const unsigned width = hi - lo;
+    int c = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) c += (h[e] - lo) <= width;
+    const uint64_t some = __ballot(c > 0);
+    return __ballot(c > 1) != 0 || (some & (some - 1)) != 0;
+}
+
 // after the selection on approximate keys: the result stands only if the winner is alone in its error band
 template <int E>
 __device__ inline void band_resolve(const unsigned (&h)[E], int n, const float *band, int p, int lane, SelectResult &res)
@@ -326,7 +400,7 @@ __device__ inline void band_resolve(const unsigned (&h)[E], int n, const float *
     const unsigned th = (unsigned)(res.thr_key >> 32);
     unsigned lo, hi;
     band_limits(th, band + 2 * p, lo, hi);
-    if (band_count<E>(h, lo, hi) > 1) {
+    if (band_crowded<E>(h, lo, hi)) {
         res.thr_key = (uint64_t)th << 32;
         res.cut = SELECT_UNRESOLVED;
     }

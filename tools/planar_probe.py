@@ -20,7 +20,7 @@ fn = lib.acoss_dev_planar_probe
 fn.restype = ctypes.c_int
 fn.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
-names = {1: "rows loads only", 2: "rows select", 11: "cols loads only", 13: "cols w/o selection", 12: "cols select"}
+names = {1: "rows loads only", 2: "rows select", 3: "rows select, made-up keys (no loads)", 11: "cols loads only", 13: "cols w/o selection", 12: "cols select"}
 res = {m: [] for m in names}
 for rnd in range(5):
     for m in names:
