@@ -4,6 +4,7 @@
 // gfx950 (CDNA4) only: wave64, DPP reductions, scalar (SGPR) broadcast of wave-uniform rows.
 #include "common.h"
 #include "wave_ops.h"
+#include "gemm_f32.h"
 #include "gemm_f64.h"
 #include "kernel_utils.h"
 #include "thresh_work.h"
@@ -238,6 +239,53 @@ __global__ __launch_bounds__(GM_THREADS) void csm_gemm_kernel(const double *__re
         [&](const int i, const int j, const double v) {
             if (i0 + i < ds.nx && j0 + j < ds.ny) {
                 const double c = fma(-2.0, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
+                out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
+            }
+        });
+}
+
+// The same for float32 features (the reference keeps the scattering features in float32, Serra09.py:187-192, and
+// get_csm follows the dtype of its inputs, CRPUtils.py:82): gemm_f32.h on v_mfma_f32_16x16x4_f32, float32 output.
+// Rows are read as 16-byte quads when the layout allows it (no roll, d a multiple of 4: the scattering case).
+// |result^2 - exact^2| <= (d + 4) 2^-24 (|x|^2 + |y|^2), the bound of any float32 dot product of d terms plus the
+// three roundings of the norms' sum and the final FMA; tests/test_gpu_stages.py compares within twice that (both
+// sides of the comparison carry it).
+template <int WM>
+__global__ __launch_bounds__(GM32_THREADS, 2) void csm_gemm32_kernel(const float *__restrict__ feats, const float *__restrict__ norms,
+                                                                     int d, const acoss_pair_desc *__restrict__ descs,
+                                                                     int tiles_m, int tiles_n, float *__restrict__ out)
+{
+    constexpr int TM = 64 * WM, TN = 128;
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm32_smem[];
+    Gemm32Smem<WM, 4> &sm = *reinterpret_cast<Gemm32Smem<WM, 4> *>(gemm32_smem);
+    const int tiles = tiles_m * tiles_n;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);      // neighbouring tiles (same x rows) share an L2
+    const int p = lb / tiles, t = lb % tiles;
+    const acoss_pair_desc ds = descs[p];
+    const int i0 = (t / tiles_n) * TM, j0 = (t % tiles_n) * TN;
+    if (i0 >= ds.nx || j0 >= ds.ny) return;
+    const bool quads = ds.shift == 0 && (d & 3) == 0 && (reinterpret_cast<uintptr_t>(feats) & 15) == 0;      // block-uniform
+    auto row_quad = [&](const int64_t row0, const int rows, const int r, const int k, const int shift) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r >= rows || k >= d) return v;
+        const float *src = feats + (row0 + r) * d;
+        if (quads) return *reinterpret_cast<const float4 *>(src + k);
+        float e[4];
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            int q = k + c - shift;                     // np.roll(chroma_i, oti) (Serra09.py:167)
+            if (q < 0) q += d;
+            e[c] = k + c < d ? src[q] : 0.f;
+        }
+        return make_float4(e[0], e[1], e[2], e[3]);
+    };
+    gemm_nt_tile_f32(
+        sm, d,
+        [&](const int r, const int k) { return row_quad(ds.x_row0 + i0, ds.nx - i0, r, k, ds.shift); },
+        [&](const int r, const int k) { return row_quad(ds.y_row0 + j0, ds.ny - j0, r, k, 0); },
+        [&](const int i, const int j, const float v) {
+            if (i0 + i < ds.nx && j0 + j < ds.ny) {
+                const float c = fmaf(-2.0f, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
                 out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
             }
         });
@@ -922,6 +970,17 @@ static int launch_csm(const T *feats, const T *norms, int d, const acoss_pair_de
             if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
             hipLaunchKernelGGL(csm_gemm_kernel, dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, feats, norms, d, descs, tm, tn, csm);
             return launch_check("csm_gemm_kernel");
+        }
+    }
+    if constexpr (sizeof(T) == 4) {
+        if (d >= 32) {        // wide float32 features: matrix cores
+            // (128 x 128 tiles, two blocks per CU: 111 TFLOP/s at 992 x 20736 x 992; 256 x 128 tiles with one block per CU: 87)
+            const int tm = ceil_div(max_nx, 128), tn = ceil_div(max_ny, 128);
+            const int64_t blocks = (int64_t)K * tm * tn;
+            if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
+            const size_t lds = sizeof(Gemm32Smem<2, 4>);
+            hipLaunchKernelGGL(csm_gemm32_kernel<2>, dim3((unsigned)blocks), dim3(GM32_THREADS), lds, st, feats, norms, d, descs, tm, tn, csm);
+            return launch_check("csm_gemm32_kernel");
         }
     }
     const int tm = ceil_div(max_nx, 16), tn = ceil_div(max_ny, 16);

@@ -313,6 +313,36 @@ def test_wide_crp_selection_paths(eng, orc):
     assert np.array_equal(res["dmax"], d)
 
 
+def test_wide_float32_feature_csm_on_matrix_cores(eng, orc):
+    """get_csm for float32 features wider than 32 (the reference keeps its scattering features in float32, Serra09.py:187-192;
+    the CSM follows the dtype, CRPUtils.py:82): the v_mfma_f32_16x16x4_f32 kernel, quads (no roll, d % 4 == 0) and the
+    element-wise loader (roll, odd d), ragged tiles.  Tolerance, on the SQUARED distances: a float32 dot product of d terms is
+    within (d + 2) u |x||y| of the exact one whatever its order (u = 2^-24), the norms' sum and the final FMA add two more
+    roundings: |c - c_exact| <= (d + 4) u (|x|^2 + |y|^2) against float64, twice that between two float32 evaluations."""
+    rng = np.random.default_rng(29)
+    u = 2.0 ** -24
+    for d, shift, (M, N) in ((32, 0, (70, 131)), (52, 0, (129, 128)), (200, 0, (300, 17)), (333, 41, (70, 131)), (64, 5, (40, 260)),
+                             (2048, 0, (150, 140))):
+        X = (np.cumsum(rng.standard_normal((M, d)), axis=0) * 0.1).astype(np.float32)
+        Y = (np.cumsum(rng.standard_normal((N, d)), axis=0) * 0.1).astype(np.float32)
+        corpus = _pair_corpus(eng, X, Y)
+        assert corpus.dtype == np.float32
+        batch = eng.PairBatch(corpus.frame_off, np.array([[0, 1]], dtype=np.int32), 1, corpus.device)
+        batch.set_shifts([shift])
+        C = eng.csm(corpus, batch)
+        assert C.dtype == eng.torch.float32
+        dsc = batch.descs[0]
+        got = C.cpu().numpy()[int(dsc["csm_off"]):int(dsc["csm_off"]) + M * int(dsc["csm_pitch"])].reshape(M, -1)[:, :N].astype(np.float64)
+        Xr = np.roll(X.astype(np.float64), shift, axis=1)
+        Y64 = Y.astype(np.float64)
+        nx, ny = np.sum(Xr * Xr, axis=1), np.sum(Y64 * Y64, axis=1)
+        exact = np.maximum(nx[:, None] + ny[None, :] - 2.0 * Xr.dot(Y64.T), 0.0)
+        bound = (d + 4) * u * (nx[:, None] + ny[None, :])
+        assert np.all(np.abs(got * got - exact) <= bound * (1 + 1e-6) + 4 * u * exact), (d, shift)      # + the rounding of sqrt, squared back
+        want = orc.get_csm(X, Y, shift).astype(np.float64)
+        assert np.all(np.abs(got * got - want * want) <= 2 * bound + 8 * u * exact), (d, shift)
+
+
 def test_wide_feature_csm_on_matrix_cores(eng, orc):
     """get_csm for float64 features wider than 32 (the scattering-feature case, Serra09.py:187): the MFMA kernel
     against the oracle, with and without a roll, ragged sizes, d not a multiple of the k-chunk; and the m = 1 chain."""
