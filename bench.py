@@ -24,7 +24,8 @@ cross-similarity + sliding-window kernel -- timed live with HIP events on the la
 and whether the GPU scores of the sampled pairs are identical; `f64_path` = the same steps with every windowed sum in
 float64 (scores must be identical); `fused` = the same steps with the masks from the fused band kernel; `plugin` = pairs/s
 through the one-call scorer (`engine.serra09_scores`); `config3`, `early_snf`, `ftm2d` = BASELINE configs 3-5 on small
-samples, each with the oracle's CPU rate and an identity check.
+samples, each with the oracle's CPU rate and an identity check; `scatter_csm` = the float32 992 x 20736 x 992 CSM of the
+scattering features (Serra09.py:187-192) on the matrix cores.
 """
 import argparse
 import json
@@ -374,6 +375,42 @@ def extras_ftm2d(engine, torch):
             "parity": {"max_abs_err_vs_oracle_8x8": err, "tolerance": 1e-12}}
 
 
+def extras_scatter_csm(engine, oracle, torch):
+    """Serra09.py:187-192: the cross-similarity matrix of 20 736-dimensional float32 scattering features, one
+    992 x 20736 x 992 float32 product per pair on the matrix cores (csm_gemm32_kernel, v_mfma_f32_16x16x4_f32)."""
+    rng = np.random.default_rng(5)
+    S, F, D = 8, 992, 20736
+    feats = rng.standard_normal((S * F, D), dtype=np.float32)
+    corpus = engine.DeviceCorpus(feats, np.arange(S + 1, dtype=np.int64) * F)
+    pairs = np.array([(i, j) for i in range(S) for j in range(S) if i < j], dtype=np.int32)
+    batch = engine.PairBatch(corpus.frame_off, pairs, 1, corpus.device)
+    out = engine.csm(corpus, batch)
+    ms = time_kernel(lambda: engine.csm(corpus, batch, out=out), torch)
+    flop = 2.0 * F * F * D * len(pairs)
+    # sampled tolerance check: 16 rows of the first pair against float64 and against the oracle's float32 get_csm
+    d0 = batch.descs[0]
+    got = out[int(d0["csm_off"]):int(d0["csm_off"]) + 16 * int(d0["csm_pitch"])].cpu().numpy().reshape(16, -1)[:, :F].astype(np.float64)
+    x, y = feats[:16], feats[F:2 * F]
+    x64, y64 = x.astype(np.float64), y.astype(np.float64)
+    nx, ny = (x64 * x64).sum(1), (y64 * y64).sum(1)
+    exact = np.maximum(nx[:, None] + ny[None, :] - 2.0 * x64.dot(y64.T), 0.0)
+    bound = (D + 4) * 2.0 ** -24 * (nx[:, None] + ny[None, :])
+    err = float(np.max(np.abs(got * got - exact) / bound))
+    t0 = time.perf_counter()
+    ref = oracle.get_csm(x, y).astype(np.float64)
+    cpu_s = time.perf_counter() - t0
+    err_o = float(np.max(np.abs(got * got - ref * ref) / bound))
+    del corpus
+    return {"workload": "%d pairs of %d x %d x %d float32 (20 736-d scattering features, Serra09.py:187-192)" % (len(pairs), F, D, F),
+            "value": round(len(pairs) / ms * 1e3, 1), "unit": "pair-CSMs/s", "ms": round(ms, 3),
+            "f32_tflops": round(flop / ms / 1e9, 1), "frac_of_f32_matrix_peak": round(flop / ms / 1e9 / F32_MATRIX_PEAK_TFLOPS, 3),
+            "cpu_baseline": {"value": round(16.0 / F / cpu_s, 4), "unit": "pair-CSMs/s", "cores": 1, "kind": "port",
+                             "sample": "16 rows of one pair through the oracle's float32 get_csm (%.2f s)" % cpu_s},
+            "parity": {"max_err_over_bound_vs_float64": round(err, 4), "max_err_over_bound_vs_oracle_f32": round(err_o, 4),
+                       "bound": "(d + 4) 2^-24 (|x|^2 + |y|^2) on squared distances; <= 1 against float64, <= 2 between two float32 evaluations",
+                       "within_tolerance": bool(err <= 1.0 and err_o <= 2.0)}}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -613,7 +650,8 @@ def main():
         torch.cuda.empty_cache()
         for key, fn in (("config3", lambda: extras_config3(engine, synth, oracle, threads, torch)),
                         ("early_snf", lambda: extras_early_snf(engine, synth, torch)),
-                        ("ftm2d", lambda: extras_ftm2d(engine, torch))):
+                        ("ftm2d", lambda: extras_ftm2d(engine, torch)),
+                        ("scatter_csm", lambda: extras_scatter_csm(engine, oracle, torch))):
             try:
                 out[key] = fn()
             except Exception as exc:           # a side block must not take the headline down

@@ -9,13 +9,17 @@ mkdir -p $O
 python3 $R/bench.py "$@" > $O/bench.log 2>&1 || exit 1
 grep -E '^\{' $O/bench.log > $O/bench.json
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline "$@" > $O/stats.log 2>&1 || exit 2
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/wr -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/wr.log 2>&1 || exit 3
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/rd -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/rd.log 2>&1 || exit 4
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/sq.log 2>&1 || exit 5
-rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline "$@" > $O/sq2.log 2>&1 || exit 6
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > $O/stats.log 2>&1 || exit 2
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/wr -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/wr.log 2>&1 || exit 3
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/rd -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/rd.log 2>&1 || exit 4
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_INSTS_SALU --kernel-trace --output-format csv -d $O/sq -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/sq.log 2>&1 || exit 5
+rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/sq2.log 2>&1 || exit 6
 cd $R && python3 tools/pmc_json.py $O/pmc.json $O/wr $O/rd $O/sq $O/sq2 > $O/pmc_table.txt
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
+# one more kernel trace with the side blocks (float64 / fused paths, configs 3-5, scattering CSM): their kernels' durations
+cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/statsx -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $O/statsx.log 2>&1 || exit 7
+cd $R && cp $O/statsx/*/*_kernel_stats.csv $O/kernel_stats_extras.csv
+rm -rf $O/statsx
 # keep the merge small
 rm -rf $O/stats $O/wr $O/rd $O/sq $O/sq2
 echo done
