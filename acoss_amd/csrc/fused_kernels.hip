@@ -388,6 +388,12 @@ constexpr int BUFFER_RSRC_WORD3 = 0x00020000;      // gfx9 raw buffer: 32-bit da
 // so that is the upper half of the bit pattern with the sign bit set).  Half the bytes of the float64 form leave the
 // chip and the selection kernels read 4 bytes per element; the low words are needed for ~0.1 % of the rows /
 // columns only, whose tied elements the fix-up kernel recomputes from the features.
+// Cache policy of the result stores (raw buffer store aux bits on gfx950: 2 = nt).  The key-word forms (4 bytes per cell:
+// a wave's stores cover lines only partly) gain from non-temporal stores -- 5.79 against 6.10 ms here, 3.3 against 3.7 ms
+// in the float32 kernel, per 4096 pairs, same buffer; the float64 form (16 bytes per lane, whole lines) loses: 7.8 against
+// 6.7 ms (tools/ab_strip.py, tools/ab_strip32.py).
+#define STRIP_STORE_POLICY (PLANAR ? 2 : 0)
+
 template <int D, int WIN, bool SQRT_OUT, int MODE = 0, bool CSM_LAYOUT = false, bool PLANAR = false>
 __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict__ xp, int max_nx,
                                                         const double *__restrict__ feats, const double *__restrict__ norms,
@@ -587,8 +593,8 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                     const uint32_t hb = (uint32_t)__double2hiint(sb) | 0x80000000u;
                     if (CHECKED) {
                         const bool row_ok = gi >= 0 && gi < M;
-                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, 0);
-                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, 0);
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, hw(col), soff, STRIP_STORE_POLICY);
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, hw(col + 1), soff, STRIP_STORE_POLICY);
                     } else {
                         // this lane's pair of the row: columns ps, ps + 1 (ps even): one 8-byte store, 512 contiguous bytes per wave
                         uint32_t h0 = ha, h1 = hb;
@@ -598,7 +604,7 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                             h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x130, 0xf, 0xf, true);   // wave_shl:1
                             ps = col + 1;
                         }
-                        if (ps >= 0 && ps < TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, orsrc, hw(ps), soff, 0);
+                        if (ps >= 0 && ps < TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2_t){h0, h1}, orsrc, hw(ps), soff, STRIP_STORE_POLICY);
                     }
                 } else {
                     const int soff = 8 * (orow0 + (t * STRIP_ROWS + q) * o_pitch);      // wave-uniform byte offset of (row, strip column 0)
@@ -608,15 +614,15 @@ __global__ __launch_bounds__(512) void crp_strip_kernel(const double *__restrict
                         if (sa == -1.25) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * (col & 63), soff, 0);
                     } else if (CHECKED) {
                         const bool row_ok = gi >= 0 && gi < M;
-                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b64(wa, orsrc, 8 * col, soff, 0);
-                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * col + 8, soff, 0);
+                        if (row_ok && col >= 0 && col < TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b64(wa, orsrc, 8 * col, soff, STRIP_STORE_POLICY);
+                        if (row_ok && col + 1 >= 0 && col + 1 < TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b64(wb, orsrc, 8 * col + 8, soff, STRIP_STORE_POLICY);
                     } else if ((q & 1) == 0) {
-                        if (col >= 0 && col < TN) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wa.x, wa.y, wb.x, wb.y}, orsrc, 8 * col, soff, 0);
+                        if (col >= 0 && col < TN) __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wa.x, wa.y, wb.x, wb.y}, orsrc, 8 * col, soff, STRIP_STORE_POLICY);
                     } else {
                         const unsigned glo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.x, 0x130, 0xf, 0xf, true);   // wave_shl:1
                         const unsigned ghi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)wa.y, 0x130, 0xf, 0xf, true);
                         if (col + 1 >= 0 && col + 1 < TN)
-                            __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wb.x, wb.y, glo, ghi}, orsrc, 8 * col + 8, soff, 0);
+                            __builtin_amdgcn_raw_buffer_store_b128((u32x4_t){wb.x, wb.y, glo, ghi}, orsrc, 8 * col + 8, soff, STRIP_STORE_POLICY);
                     }
                 }
             }

@@ -68,7 +68,13 @@ __global__ __launch_bounds__(64) void select_fix_side_kernel(const double *__res
 }
 
 // ---- rows ------------------------------------------------------------------------------------------------
-constexpr int PL_ROWS_PER_WAVE = 16;
+#ifndef PL_RPW
+#define PL_RPW 16
+#endif
+#ifndef PL_WARM32
+#define PL_WARM32 3          // float32 keys: the same window of values is 2^3 as many keys as float64 high words
+#endif
+constexpr int PL_ROWS_PER_WAVE = PL_RPW;
 
 // MODE (development probes): 1 = loads only
 template <int MODE = 0, int E = 16>
@@ -92,7 +98,7 @@ __global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kerne
     unsigned *hist = hist_all + wave * HIST_WORDS;
     hist_clear(hist, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
-    HistWarm warm{0, (E == 16 ? HIST256_SHIFT0 : HIST_WARM_SHIFT0) + (w.band != nullptr ? 3 : 0)};
+    HistWarm warm{0, (E == 16 ? HIST256_SHIFT0 : HIST_WARM_SHIFT0) + (w.band != nullptr ? PL_WARM32 : 0)};
     const uint64_t valid = planar_slot_valid<E>(N, lane);
     const bool wide = N > (E - 1) * 64;       // wave-uniform: only the last slot can run past the row
     for (int i = r0; i < r1; i++) {
@@ -110,8 +116,8 @@ __global__ __launch_bounds__(256, E == 16 ? 8 : 4) void select_rows_planar_kerne
         if (wide) {
             // wave-uniform row pointer + one lane offset + immediates: 256 contiguous bytes per load instruction
 #pragma unroll
-            for (int e = 0; e < E - 1; e++) h[e] = row[(unsigned)(e * 64 + lane)];
-            h[E - 1] = row[(unsigned)min((E - 1) * 64 + lane, N - 1)];
+            for (int e = 0; e < E - 1; e++) h[e] = __builtin_nontemporal_load(row + (unsigned)(e * 64 + lane));      // read once: no cache allocation
+            h[E - 1] = __builtin_nontemporal_load(row + (unsigned)min((E - 1) * 64 + lane, N - 1));
         } else {
             // (cold path: the lane number is laundered through an empty asm so that the sixteen clamped offsets are
             // computed here instead of being hoisted in front of the row loop, where they would set the register
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(512, 4) void select_cols_planar_kernel(const uint32
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<16>(M, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
-    HistWarm warm{0, HIST256_SHIFT0 + (w.band != nullptr ? 3 : 0)};
+    HistWarm warm{0, HIST256_SHIFT0 + (w.band != nullptr ? PL_WARM32 : 0)};
     auto column = [&](const unsigned (&h)[16], const int j) {
         SelectResult res;
         if (MODE == 2) { res.thr_key = ((uint64_t)__builtin_amdgcn_readfirstlane((int)h[1]) << 32) | 0xffffffffull; res.cut = 0x7fffffff; }
@@ -315,7 +321,7 @@ __global__ __launch_bounds__(64 * COLS) void select_cols_planar_wide_kernel(cons
     const int k = knn_count(k_mode, kv, M);
     const uint64_t valid = planar_slot_valid<32>(M, lane);
     // (float32 keys carry 23 mantissa bits where float64 high words carry 20: the same window of values is 8x as many keys)
-    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? 3 : 0)};
+    HistWarm warm{0, HIST_WARM_SHIFT0 + (w.band != nullptr ? PL_WARM32 : 0)};
     SelectResult res;
     if (!planar_trivial(k, M, res)) {
         res = wave_select_hist_u32<32>(h, M, k, hist, lane, warm);

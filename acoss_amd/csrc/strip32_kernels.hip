@@ -40,6 +40,12 @@ constexpr int S32_CPAD = 8;
 constexpr int S32_RSRC_WORD3 = 0x00020000;
 
 // MODE (development probe): 1 = no result stores
+// cache policy of the key stores (raw buffer store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): the matrix is written
+// once and read back from HBM long after it has left every cache
+#ifndef S32_STORE_POLICY
+#define S32_STORE_POLICY 2
+#endif
+
 template <int D, int MODE = 0>
 __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restrict__ xp, int max_nx,
                                                           const float *__restrict__ feats, const float *__restrict__ norms,
@@ -152,8 +158,8 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
                 if (s.x == -1.25f) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, 4 * (col & 63), soff, 0);
             } else if (CHECKED) {
                 const bool row_ok = gi >= 0 && gi < M;
-                if (row_ok && col >= 0 && col < S32_TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, 4 * col, soff, 0);
-                if (row_ok && col + 1 >= 0 && col + 1 < S32_TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, 4 * (col + 1), soff, 0);
+                if (row_ok && col >= 0 && col < S32_TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, 4 * col, soff, S32_STORE_POLICY);
+                if (row_ok && col + 1 >= 0 && col + 1 < S32_TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, 4 * (col + 1), soff, S32_STORE_POLICY);
             } else {
                 uint32_t h0 = ha, h1 = hb;
                 int ps = col;
@@ -162,7 +168,7 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
                     h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x130, 0xf, 0xf, true);   // wave_shl:1
                     ps = col + 1;
                 }
-                if (ps >= 0 && ps < S32_TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){h0, h1}, orsrc, 4 * ps, soff, 0);
+                if (ps >= 0 && ps < S32_TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){h0, h1}, orsrc, 4 * ps, soff, S32_STORE_POLICY);
             }
         }
         // carry the last HALO C rows over to the next step: read before the barrier, write after it
