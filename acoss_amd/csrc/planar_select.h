@@ -223,9 +223,7 @@ __device__ inline bool band_crowded(const unsigned (&h)[E], unsigned lo, unsigne
 // unsigned saturating subtraction (v_sub_u32 with the clamp bit): max(a, b) - b in one instruction; b wave-uniform
 __device__ inline unsigned sat_sub_u32(unsigned a, unsigned b_uniform)
 {
-    unsigned d;
-    asm("v_sub_u32_e64 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "s"(b_uniform));
-    return d;
+    return __builtin_elementwise_sub_sat(a, b_uniform);
 }
 
 // Instruction budget: at eight waves per SIMD these kernels are bound by instruction issue, not by latency (the
@@ -259,8 +257,13 @@ __device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], 
             unsigned mn = 0xffffffffu, mx = 0u;
 #pragma unroll
             for (int e = 0; e < E; e++) {
-                mn = min(mn, h[e]);
-                mx = max(mx, h[e] == PLANAR_PAD ? 0u : h[e]);
+                // (the key goes through an opaque volatile asm: otherwise the per-lane minimum and maximum -- loop-invariant
+                // and free of side effects -- are hoisted in front of the pass loop and computed for EVERY row, 56
+                // instructions that only the first row of a wave and the rows with a failed prediction need)
+                unsigned v = h[e];
+                asm volatile("" : "+v"(v));
+                mn = min(mn, v);
+                mx = max(mx, v == PLANAR_PAD ? 0u : v);
             }
             mn = wave_umin(mn);
             mx = wave_umax(mx);
@@ -271,8 +274,7 @@ __device__ inline SelectResult wave_select_hist256_u32(const unsigned (&h)[16], 
         const unsigned spill = (unsigned)(HIST256_BINS + lane);
 #pragma unroll
         for (int e = 0; e < E; e++) {
-            unsigned b = min(sat_sub_u32(h[e], lo0) >> shift, spill);      // above the window or padding: a spill word
-            asm("" : "+v"(b));      // opaque: hipcc 7.2 crashes in instruction selection on the folded LDS address
+            const unsigned b = min(sat_sub_u32(h[e], lo0) >> shift, spill);      // above the window or padding: a spill word
             bin[e] = b;
             atomicAdd(&hist[b], 1u);
         }
