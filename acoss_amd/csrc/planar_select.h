@@ -33,14 +33,12 @@ __device__ inline void planar_put_lanes4_u64(unsigned &lo, unsigned &hi, uint64_
           "n"(e), "n"(e + 1), "n"(e + 2), "n"(e + 3));
 }
 
-// lane e (< E) = lane mask of "position e*64 + lane exists"
+// lane e (< E) = lane mask of "position e*64 + lane exists" (computed in the lane: no ballots)
 template <int E>
 __device__ inline uint64_t planar_slot_valid(int n, int lane)
 {
-    unsigned lo = 0, hi = 0;
-#pragma unroll
-    for (int e = 0; e < E; e++) planar_put_lane_u64(lo, hi, __ballot(e * 64 + lane < n), e);
-    return ((uint64_t)hi << 32) | lo;
+    const int rem = n - 64 * lane;          // positions of word `lane` that exist
+    return rem >= 64 ? ~0ull : (rem <= 0 ? 0ull : ((1ull << rem) - 1ull));
 }
 
 // Padding convention of the 16-keys-per-lane selection (wave_select_hist256_u32): positions >= n hold PLANAR_PAD, a key
