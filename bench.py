@@ -117,16 +117,17 @@ class Runner(object):
             self.bands = [engine.planar32_band(corpus, b) for b in batches]
         if path == "fused":
             self.bands = [engine.planar32_band(corpus, b, fused=True) for b in batches]
-        # The strip kernel's time depends on which allocation it writes (3.9 vs 4.4 ms for two
-        # 16 GB buffers in one process, any offset inside either gives the same time).  Try a few placements for
-        # the big intermediate once, before anything is timed, and keep the fastest.
+        # The times of the kernels that write and read the big intermediate depend on which allocation it lives in (DESIGN.md
+        # section 4a: the strip kernel 3.65-3.93 ms, the row selection 2.90-3.37 ms for eight 16 GB buffers in one process,
+        # moving against each other; any offset inside a buffer gives the same times).  Try a few placements once, before
+        # anything is timed, and keep the one with the shortest strip + selection time.
         self.placement_ms = None
         if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
             b0 = batches[0]
             engine.oti(corpus, b0)
             cands, times = [self.S], []
             try:
-                for _ in range(2):
+                for _ in range(3):
                     cands.append(torch.empty(self.S.numel(), dtype=torch.float64, device=dev))
             except RuntimeError:
                 pass
@@ -138,8 +139,10 @@ class Runner(object):
                     e0.record()
                     if path == "fast32":
                         engine.crp_planar32(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp), out=planes)
+                        engine.mask_bits_planar32(planes, self.bands[0], corpus, b0, kappa, True, out=self.bits, work=self.work)
                     else:
                         engine.crp_planar(corpus, b0, engine.pack_x(corpus, b0, out=self.xp), out=planes)
+                        engine.mask_bits_planar(planes, corpus, b0, kappa, True, out=self.bits, work=self.work)
                     e1.record()
                     torch.cuda.synchronize()
                     if rep:
