@@ -593,7 +593,7 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     """The scorer's device scratch (grow-only, shared by successive calls).  The kernels that write and read the big
     intermediate run 5-10 % faster or slower depending on WHICH allocation it lives in (a property of
     the allocation's physical backing, stable for its lifetime), so a new buffer of more than 4 GiB is chosen among
-    ACOSS_SCRATCH_TRIALS (default 3, as memory allows) candidates by timing one batch of the call at hand in each."""
+    ACOSS_SCRATCH_TRIALS (default 4, as memory allows) candidates by timing one batch of the call at hand in each."""
     key = ("scorer", str(device), torch.uint8)
     buf = _SCRATCH.get(key)
     if buf is not None and buf.numel() >= need:
@@ -602,7 +602,7 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     buf = None
     torch.cuda.empty_cache()
     size = int(need * 1.05) + 16
-    trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "3")))
+    trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "4")))
     free_b = torch.cuda.mem_get_info(device)[0]
     trials = max(1, min(trials, int(0.6 * free_b // max(size, 1))))
     if size < (4 << 30) or trials == 1:

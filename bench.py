@@ -20,7 +20,7 @@ an error.
 Prints ONE JSON line on rank 0.  `roofline` describes the dominant HBM-bound kernel of the timed path -- the
 cross-similarity + sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region
 (`stage_ms` has every stage).  Beside the headline (rank 0, one GPU; `--no-extras` skips them):
-`roofline_csm_*` = the stand-alone get_csm kernels; `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores
+`roofline_csm_*` = the stand-alone get_csm kernels; `roofline_selection` = the row and column selection kernels' read rates; `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores
 and whether the GPU scores of the sampled pairs are identical; `f64_path` = the same steps with every windowed sum in
 float64 (scores must be identical); `fused` = the same steps with the masks from the fused band kernel; `plugin` = pairs/s
 through the one-call scorer (`engine.serra09_scores`); `config3`, `early_snf`, `ftm2d` = BASELINE configs 3-5 on small
@@ -562,6 +562,21 @@ def main():
         out["hbm_write_ceiling"] = {"kernel": "torch fill_ of the CSM buffer, %d bytes (plain streaming stores)" % fb,
                                     "achieved": round(fb / fms / 1e6, 1), "unit": "GB/s", "avg_launch_ms": round(fms, 4)}
         del C, xp
+        if args.path == "fast32":
+            # the two selection kernels that read the key matrix back (CRPUtils.py:169-219), on the timed placement: the
+            # non-mutual call runs rows + refinement + combine, the mutual one adds the column kernel
+            planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
+            engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
+            t_rows = time_kernel(lambda: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, False, out=runner.bits, work=runner.work), torch)
+            t_both = time_kernel(lambda: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, True, out=runner.bits, work=runner.work), torch)
+            kb = 4.0 * float(np.sum((b.descs["nx"].astype(np.float64) - m + 1) * (b.descs["ny"].astype(np.float64) - m + 1)))
+            out["roofline_selection"] = {
+                "kernels": "select_rows_planar_kernel (+ select_fix_side + combine_bits: the non-mutual call) / select_cols_planar_kernel "
+                           "(mutual call minus non-mutual call); each reads the key matrix once, 4 B / cell",
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_launch": kb,
+                "rows_call_ms": round(t_rows, 4), "rows_achieved": round(kb / t_rows / 1e6, 1), "rows_frac": round(kb / t_rows / 1e6 / HBM_PEAK_GBS, 4),
+                "cols_ms": round(t_both - t_rows, 4), "cols_achieved": round(kb / (t_both - t_rows) / 1e6, 1),
+                "cols_frac": round(kb / (t_both - t_rows) / 1e6 / HBM_PEAK_GBS, 4)}
     threads = max(1, min(os.cpu_count() or 1, 16))
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle
