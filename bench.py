@@ -125,12 +125,25 @@ class Runner(object):
         if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
             b0 = batches[0]
             engine.oti(corpus, b0)
-            cands, times = [self.S], []
-            try:
-                for _ in range(max(0, int(os.environ.get("ACOSS_BENCH_PLACEMENTS", "4")) - 1)):
-                    cands.append(torch.empty(self.S.numel(), dtype=torch.float64, device=dev))
-            except RuntimeError:
-                pass
+            # candidates: windows of ONE large arena, 8 GiB apart (regions of an arena differ as much as separate allocations
+            # do, tools/placement_probe4.py, and a scan costs no further allocations), the buffer allocated above among them
+            win_bytes = self.S.numel() * 8
+            free_b = torch.cuda.mem_get_info(dev)[0]
+            arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "112"))
+            arena_bytes = int(min(arena_gb * (1 << 30), 0.55 * free_b))
+            cands, where = [self.S], ["own"]
+            self.arena = None
+            if arena_bytes >= 2 * win_bytes:
+                try:
+                    self.arena = torch.empty(arena_bytes // 8, dtype=torch.float64, device=dev)
+                except RuntimeError:
+                    self.arena = None
+            if self.arena is not None:
+                step = 8 << 30
+                for off in range(0, arena_bytes - win_bytes + 1, step):
+                    cands.append(self.arena[off // 8: off // 8 + self.S.numel()])
+                    where.append("%d" % (off >> 30))
+            times = []
             for buf in cands:
                 planes = buf.view(torch.int32)[:engine.planar_elems(b0)]
                 best = 1e9
@@ -148,9 +161,12 @@ class Runner(object):
                     if rep:
                         best = min(best, e0.elapsed_time(e1))
                 times.append(best)
-            self.S = cands[int(np.argmin(times))]
-            self.placement_ms = [round(t, 3) for t in times]
+            pick = int(np.argmin(times))
+            self.S = cands[pick]
+            self.placement_ms = {"candidates": where, "strip_plus_selection_ms": [round(t, 3) for t in times], "picked": where[pick]}
             del cands
+            if pick == 0:
+                self.arena = None
             torch.cuda.empty_cache()
         self.plans = []
         for b in batches:
