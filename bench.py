@@ -69,6 +69,9 @@ STAGES = {p: ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"] for p in ("fast3
 STAGES["staged"] = ["oti", "csm", "sliding", "binarize", "qmax"]
 
 
+_ARENA = {}
+
+
 class Runner(object):
     """One step.  fast32 / fast: OTI -> pack_x -> crp (CSM + sliding window in one kernel; float32 keys or float64 key high
     words) -> mask_bits (row and column kNN selection emitting bit vectors by ballot, refinement, transposed and ANDed into
@@ -125,21 +128,26 @@ class Runner(object):
         if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
             b0 = batches[0]
             engine.oti(corpus, b0)
-            # candidates: windows of ONE large arena, 8 GiB apart (regions of an arena differ as much as separate allocations
+            # candidates: windows of ONE large arena, 4 GiB apart (regions of an arena differ as much as separate allocations
             # do, tools/placement_probe4.py, and a scan costs no further allocations), the buffer allocated above among them
             win_bytes = self.S.numel() * 8
             free_b = torch.cuda.mem_get_info(dev)[0]
-            arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "112"))
-            arena_bytes = int(min(arena_gb * (1 << 30), 0.55 * free_b))
+            arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "160"))
+            arena_bytes = int(min(arena_gb * (1 << 30), 0.6 * free_b))
             cands, where = [self.S], ["own"]
-            self.arena = None
-            if arena_bytes >= 2 * win_bytes:
+            self.arena = _ARENA.get(str(dev))             # one arena per process and device, shared by the side blocks' runners
+            if self.arena is not None and self.arena.numel() * 8 < 2 * win_bytes:
+                self.arena = None
+            if self.arena is None and arena_bytes >= 2 * win_bytes:
                 try:
                     self.arena = torch.empty(arena_bytes // 8, dtype=torch.float64, device=dev)
+                    _ARENA[str(dev)] = self.arena
                 except RuntimeError:
                     self.arena = None
             if self.arena is not None:
-                step = 8 << 30
+                arena_bytes = self.arena.numel() * 8
+            if self.arena is not None:
+                step = int(os.environ.get("ACOSS_BENCH_ARENA_STEP_GB", "4")) << 30
                 for off in range(0, arena_bytes - win_bytes + 1, step):
                     cands.append(self.arena[off // 8: off // 8 + self.S.numel()])
                     where.append("%d" % (off >> 30))
@@ -165,8 +173,6 @@ class Runner(object):
             self.S = cands[pick]
             self.placement_ms = {"candidates": where, "strip_plus_selection_ms": [round(t, 3) for t in times], "picked": where[pick]}
             del cands
-            if pick == 0:
-                self.arena = None
             torch.cuda.empty_cache()
         self.plans = []
         for b in batches:
