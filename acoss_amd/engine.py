@@ -593,7 +593,8 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     """The scorer's device scratch (grow-only, shared by successive calls).  The kernels that write and read the big
     intermediate run 5-10 % faster or slower depending on WHICH allocation it lives in (a property of
     the allocation's physical backing, stable for its lifetime), so a new buffer of more than 4 GiB is chosen among
-    ACOSS_SCRATCH_TRIALS (default 4, as memory allows) candidates by timing one batch of the call at hand in each."""
+    ACOSS_SCRATCH_TRIALS (default 4, as memory allows) candidates by timing one batch of the call at hand in each;
+    ACOSS_SCRATCH_ARENA_GB=<n> scans the windows of one n-GB arena instead."""
     key = ("scorer", str(device), torch.uint8)
     buf = _SCRATCH.get(key)
     if buf is not None and buf.numel() >= need:
@@ -605,8 +606,31 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "4")))
     free_b = torch.cuda.mem_get_info(device)[0]
     trials = max(1, min(trials, int(0.6 * free_b // max(size, 1))))
-    if size < (4 << 30) or trials == 1:
+    arena_gb = float(os.environ.get("ACOSS_SCRATCH_ARENA_GB", "0"))
+    arena_b = int(min(arena_gb * (1 << 30), 0.6 * free_b))
+    if size < (4 << 30) or (trials == 1 and arena_b < 2 * size):
         buf = torch.empty(size, dtype=torch.uint8, device=device)
+    elif arena_b >= 2 * size:
+        # opt-in: windows of one large arena, 4 GiB apart (a dedicated GPU with memory to spare: what bench.py does)
+        arena = torch.empty(arena_b, dtype=torch.uint8, device=device)
+        sample = np.ascontiguousarray(pairs[:min(len(pairs), 4096)])
+        sink = np.zeros(len(sample))
+        best_t, best_off = float("inf"), 0
+        for off in range(0, arena_b - size + 1, 4 << 30):
+            c = arena[off: off + size]
+            t = float("inf")
+            for rep in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                check(lib.acoss_serra09_scores(h, sample.ctypes.data, len(sample), m, kappa, int(do_oti), 1, bp, _ptr(c), c.numel(),
+                                               sink.ctypes.data, None, None, _stream()), "serra09_scores (placement trial)")
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:
+                    t = min(t, e0.elapsed_time(e1))
+            if t < best_t:
+                best_t, best_off = t, off
+        buf = arena[best_off: best_off + size]         # (the view keeps the arena alive)
     else:
         sample = np.ascontiguousarray(pairs[:min(len(pairs), 4096)])
         sink = np.zeros(len(sample))
