@@ -219,6 +219,7 @@ class CoverAlgorithm(object):
                 for similarity_type in self.Ds:
                     self.Ds[similarity_type] += self.Ds[similarity_type].T     # :180-182
             if rank == 0:
+                os.makedirs(self.cachedir, exist_ok=True)
                 np.savez(dump, **{k: np.asarray(v) for k, v in self.Ds.items()})
         print("Elapsed Time All Pairwise: %.3g" % (time.time() - tic))
 

@@ -75,6 +75,9 @@ class Serra09(CoverAlgorithm):
                 mfcc = getattr(self.corpus, "mfcc", None)
                 if mfcc is not None:
                     out['mfcc'] = mfcc[i]
+                ssms = getattr(self.corpus, "ssms", None)           # precomputed (n - m + 1, d) scattering features
+                if ssms is not None:
+                    out['ssms'] = ssms[i]
                 self.all_feats[i] = out
                 return out
             chroma = feats[self.chroma_type]
@@ -105,14 +108,15 @@ class Serra09(CoverAlgorithm):
     # ------------------------------------------------------------------------------------------
     def _device_corpus(self, key, songs):
         """Frames-major device copy of feature `key` for the given songs (cached while the song set
-        does not grow).  Returns (DeviceCorpus, {song index -> position})."""
+        does not grow).  Returns (DeviceCorpus, position of every song in it or -1: int32 array of N)."""
         cached = self._dev.get(key)
-        if cached is not None and set(songs) <= set(cached[1]):
+        if cached is not None and np.all(cached[1][songs] >= 0):
             return cached
-        songs = sorted(set(songs) | (set(cached[1]) if cached is not None else set()))
+        have = np.flatnonzero(cached[1] >= 0) if cached is not None else np.zeros(0, dtype=np.int64)
+        songs = np.union1d(songs, have)
         mats, g = [], []
         for s in songs:
-            f = self.load_features(s)
+            f = self.load_features(int(s))
             x = f[key]
             mats.append(np.ascontiguousarray(x.T if key != 'ssms' else x))      # (n, d) frames-major
             if key == 'chroma':
@@ -122,14 +126,14 @@ class Serra09(CoverAlgorithm):
         off = np.zeros(len(mats) + 1, dtype=np.int64)
         off[1:] = np.cumsum([mm.shape[0] for mm in mats])
         corpus = engine.DeviceCorpus(feats, off, gchroma=np.stack(g) if g else None)
-        self._dev[key] = (corpus, {s: k for k, s in enumerate(songs)})
+        where = np.full(max(self.N, int(songs.max()) + 1), -1, dtype=np.int32)
+        where[songs] = np.arange(len(songs), dtype=np.int32)
+        self._dev[key] = (corpus, where)
         return self._dev[key]
 
     def _chain(self, key, idxs, win, do_oti):
-        songs = np.unique(idxs)
-        corpus, where = self._device_corpus(key, [int(s) for s in songs])
-        local = np.array([[where[int(a)], where[int(b)]] for a, b in idxs], dtype=np.int32)
-        return engine.serra09_scores(corpus, local, m=win, kappa=self.kappa, do_oti=do_oti)
+        corpus, where = self._device_corpus(key, np.unique(idxs).astype(np.int64))
+        return engine.serra09_scores(corpus, where[idxs], m=win, kappa=self.kappa, do_oti=do_oti)
 
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)

@@ -16,12 +16,15 @@
 
 #include <algorithm>
 #include <map>
+#include <mutex>
 #include <vector>
 
 struct acoss_corpus {
     int n_songs = 0, d = 0, nbins = 0;
     int64_t n_frames = 0;
     bool owns = false, f32_ok = false;
+    bool force_f64 = false;                     // ACOSS_SCORER_F64, read once when the handle is made
+    std::mutex call_mutex;                      // the staging below belongs to one acoss_serra09_scores call at a time
     std::vector<int64_t> frame_off;
     std::vector<double> norms_scaled;           // squared norms of the centred, scaled frames (float64, host)
     double *feats = nullptr, *norms = nullptr, *gchroma = nullptr;      // device
@@ -197,6 +200,8 @@ int acoss_corpus_wrap(const double *feats, const double *norms, const double *gc
     c->f32 = const_cast<float *>(f32);
     c->n32 = const_cast<float *>(n32);
     c->f32_ok = f32 && n32 && norms_scaled;
+    const char *env = getenv("ACOSS_SCORER_F64");
+    c->force_f64 = env && env[0] && strcmp(env, "0") != 0;
     if (c->f32_ok) c->norms_scaled.assign(norms_scaled, norms_scaled + c->n_frames);
     *out = c;
     return ACOSS_OK;
@@ -290,6 +295,8 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
     }
     if (do_oti && !c->gchroma) { set_error("serra09_scores: do_oti without global chroma in the corpus"); return ACOSS_EINVAL; }
     if (K == 0) return ACOSS_OK;
+    // calls on one handle are serialised (they share its pinned staging); calls on different handles run concurrently
+    std::lock_guard<std::mutex> one_call_at_a_time(c->call_mutex);
     std::vector<BatchPlan> plan;
     int rc = plan_batches(c, pairs, K, win, batch_pairs, plan);
     if (rc != ACOSS_OK) return rc;
@@ -319,7 +326,7 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
         float *d_band = (float *)(base + v.band), *d_scores = (float *)(base + v.scores);
         ACOSS_HIP(hipMemcpyAsync(d_descs, hd, sizeof(acoss_pair_desc) * (size_t)B, hipMemcpyHostToDevice, st));
         if (do_oti) { rc = acoss_oti_batch(c->gchroma, c->nbins, d_descs, B, st); if (rc) return rc; }
-        const bool use32 = cls == 0 && c->f32_ok && !getenv("ACOSS_SCORER_F64");
+        const bool use32 = cls == 0 && c->f32_ok && !c->force_f64;
         uint64_t *bits = (uint64_t *)(base + v.bits);
         if (cls <= 1) {
             if (use32) {

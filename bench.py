@@ -436,6 +436,131 @@ def extras_scatter_csm(engine, oracle, torch):
                        "within_tolerance": bool(err <= 1.0 and err_o <= 2.0)}}
 
 
+def extras_full_job(corpus_h, torch, tmpdir):
+    """BASELINE.json:metric's second half, "MAP vs ref": the WHOLE config-2 job as the reference's driver runs it
+    (Serra09.py:231-234): Serra09.all_pairwise(symmetric=True) over all 499 500 pairs (chroma qmax AND dmax per pair, as
+    Serra09.similarity computes them, Serra09.py:166-175), Ds += Ds.T, then getEvalStatistics -- wall time end to end,
+    host planning, D2H, the score matrices and the evaluation included.  And the reference's own numbers for the 64-song
+    slice of the same corpus (tests/golden/config2_slice64.npz, generated by running the reference): scores and
+    (MR, MRR, MDR, MAP, Top-k) must be identical."""
+    import contextlib
+    import io
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    cwd = os.getcwd()
+    os.chdir(tmpdir)
+    try:
+        out = {}
+        g = np.load(os.path.join(ROOT, "tests", "golden", "config2_slice64.npz"))
+        n = int(g["n_songs"])
+        sl = synth.make_corpus(n // 4, 4, n_frames=1000, seed=20260)
+        with contextlib.redirect_stdout(io.StringIO()):
+            alg = Serra09(sl, shortname="bench_slice", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
+            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            stats = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=True) for k in ("chroma_qmax", "chroma_dmax")}
+        pairs = synth.all_pairs(n)
+        same_scores = all(np.array_equal(np.asarray(alg.Ds[k])[pairs[:, 0], pairs[:, 1]], g[k].astype(np.float32))
+                          for k in ("chroma_qmax", "chroma_dmax"))
+        same_stats = all(np.array_equal(np.array(list(stats[k][:4]) + list(stats[k][4])), g["stats_" + k.split("_")[1]])
+                         for k in ("chroma_qmax", "chroma_dmax"))
+        out["slice64_vs_reference"] = {"pairs": int(len(pairs)), "scores_identical": bool(same_scores),
+                                       "MAP": float(stats["chroma_qmax"][3]), "reference_MAP": float(g["stats_qmax"][3]),
+                                       "map_equals_reference": bool(same_stats),
+                                       "fixture": "tests/golden/config2_slice64.npz (reference chain + reference getEvalStatistics)"}
+        del alg
+        with contextlib.redirect_stdout(io.StringIO()):
+            alg = Serra09(corpus_h, shortname="bench_full", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
+            alg.all_pairwise(symmetric=True, batch_pairs=65536)          # warm: device corpus, scratch of the final size
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            res = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=True) for k in ("chroma_qmax", "chroma_dmax")}
+            t2 = time.perf_counter()
+        K = corpus_h.n_songs * (corpus_h.n_songs - 1) // 2
+        out.update({"call": "Serra09.all_pairwise(symmetric=True) + getEvalStatistics(on_gpu=True) x 2 keys, %d songs, %d pairs, "
+                            "chroma_qmax and chroma_dmax per pair" % (corpus_h.n_songs, K),
+                    "all_pairwise_seconds": round(t1 - t0, 3), "eval_seconds": round(t2 - t1, 3),
+                    "value": round(K / (t2 - t0), 1), "unit": "pairs/s end to end (two recurrences per pair)",
+                    "MAP_chroma_qmax": float(res["chroma_qmax"][3]), "MAP_chroma_dmax": float(res["chroma_dmax"][3]),
+                    "MR_chroma_qmax": float(res["chroma_qmax"][0]), "top1_chroma_qmax": float(res["chroma_qmax"][4][0]),
+                    "map_equals_reference": bool(same_stats and same_scores)})
+        return out
+    finally:
+        os.chdir(cwd)
+
+
+def extras_plugin_similarity(corpus_h, all_pairs, oracle, threads, torch, tmpdir):
+    """The plugin as the reference's drivers call it: Serra09.similarity(idxs) (Serra09.py:158-196) -- chroma with OTI and
+    MFCC without, qmax + dmax each -- on 32 768 config-2 pairs, with a synthetic 13-coefficient float32 MFCC stream (the
+    reference's mfcc_htk is float32; its CSM is then formed in float32 and the window sums in float64,
+    Serra09.py:178-179), sampled against the oracle."""
+    import contextlib
+    import io
+    import warnings
+    from acoss_amd.Serra09 import Serra09
+    rng = np.random.default_rng(13)
+    corpus_h.mfcc = [np.ascontiguousarray(np.cumsum(rng.standard_normal((corpus_h.song(i).shape[0], 13)), axis=0).astype(np.float32).T)
+                     for i in range(corpus_h.n_songs)]
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            alg = Serra09(corpus_h, shortname="bench_plugin", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
+            idxs = all_pairs[np.random.default_rng(1).permutation(len(all_pairs))[:32768]].astype(np.int64)
+            alg.similarity(idxs)                    # warm: device corpora, scratch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            sims = alg.similarity(idxs)
+            el = time.perf_counter() - t0
+        n_chk = 4 * threads
+        q, d, _ = oracle.serra09_pairs(corpus_h.feats, corpus_h.frame_off, corpus_h.gchroma, idxs[:n_chk].astype(np.int32), nthreads=threads)
+        ok = bool(np.array_equal(sims["chroma_qmax"][:n_chk], q) and np.array_equal(sims["chroma_dmax"][:n_chk], d))
+        ok_m = True
+        for t in range(3):
+            a, b = corpus_h.mfcc[idxs[t, 0]].T, corpus_h.mfcc[idxs[t, 1]].T
+            B = oracle.csm_to_binary_mutual(oracle.sliding_csm(oracle.get_csm(np.ascontiguousarray(a), np.ascontiguousarray(b)), 9), 0.095)
+            M, N = B.shape
+            D = np.zeros(M * N, dtype=np.float32)
+            Bf = np.ascontiguousarray(B.flatten())
+            ok_m = ok_m and sims["mfcc_qmax"][t] == oracle.qmax(Bf, D, M, N) / (M + N) and sims["mfcc_dmax"][t] == oracle.dmax(Bf, D, M, N) / (M + N)
+        return {"call": "Serra09.similarity(idxs): chroma (OTI) qmax + dmax and MFCC (13-d float32, no OTI) qmax + dmax, %d pairs in one call" % len(idxs),
+                "value": round(len(idxs) / el, 1), "unit": "pairs/s (4 scores per pair)",
+                "pair_scores_per_s": round(4 * len(idxs) / el, 1), "seconds": round(el, 3),
+                "parity": {"chroma_checked_pairs": int(n_chk), "chroma_identical": ok, "mfcc_checked_pairs": 3, "mfcc_identical": bool(ok_m)}}
+    finally:
+        del corpus_h.mfcc
+
+
+def extras_scatter_chain(engine, oracle, torch):
+    """Serra09.py:186-192 end to end: float32 992 x 20 736 scattering-shaped features -> get_csm on the float32 matrix cores
+    -> mutual mask (no window) -> qmax + dmax.  Smooth features (random walk in time) so the masks do not hang on float32
+    rounding; one pair checked against the oracle's float32 chain."""
+    rng = np.random.default_rng(6)
+    S, F, D = 6, 992, 20736
+    ss = [(np.cumsum(rng.standard_normal((F, D), dtype=np.float32), axis=0) / 8.0).astype(np.float32) for _ in range(S)]
+    corpus = engine.DeviceCorpus(np.concatenate(ss), np.arange(S + 1, dtype=np.int64) * F)
+    pairs = np.array([(i, j) for i in range(S) for j in range(S) if i < j], dtype=np.int32)
+    engine.serra09_scores(corpus, pairs[:3], m=1, kappa=0.095, do_oti=False)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    got = engine.serra09_scores(corpus, pairs, m=1, kappa=0.095, do_oti=False)
+    el = time.perf_counter() - t0
+    # the oracle's float32 CSM of one pair costs 20 GFLOP of scalar C: check 160 x 160 frames of the first pair
+    sub = engine.DeviceCorpus(np.concatenate([ss[0][:160], ss[1][:160]]), np.array([0, 160, 320], dtype=np.int64))
+    g1 = engine.serra09_scores(sub, np.array([[0, 1]], dtype=np.int32), m=1, kappa=0.095, do_oti=False)
+    B = oracle.csm_to_binary_mutual(oracle.get_csm(ss[0][:160], ss[1][:160]), 0.095)
+    Dm = np.zeros(160 * 160, dtype=np.float32)
+    Bf = np.ascontiguousarray(B.flatten())
+    q = oracle.qmax(Bf, Dm, 160, 160) / 320.0
+    d = oracle.dmax(Bf, Dm, 160, 160) / 320.0
+    del corpus, sub
+    return {"workload": "%d pairs of %d x %d float32 features: CSM (%d GFLOP per pair) + mutual mask + qmax + dmax" % (len(pairs), F, D, round(2.0 * F * F * D / 1e9)),
+            "value": round(len(pairs) / el, 1), "unit": "pairs/s (ssms_scatter_qmax + ssms_scatter_dmax)", "seconds": round(el, 3),
+            "parity": {"checked": "160 x 160 frames of one pair against the oracle's float32 get_csm + mask + alignment",
+                       "identical": bool(g1["qmax"][0] == q and g1["dmax"][0] == d), "scores_nonzero": bool(np.any(got["qmax"] > 0))}}
+
+
 def main():
     args = parse()
     if args.gpus < 1:
@@ -600,7 +725,8 @@ def main():
                 "cols_ms": round(t_both - t_rows, 4), "cols_achieved": round(kb / (t_both - t_rows) / 1e6, 1),
                 "cols_frac": round(kb / (t_both - t_rows) / 1e6 / HBM_PEAK_GBS, 4)}
     threads = max(1, min(os.cpu_count() or 1, 16))
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not args.no_cpu_baseline:
+        # (N > 1: rank 0 computes it after the timed region, the other ranks are done)
         from oracle import oracle
         n_cpu = args.cpu_pairs or min(512 * threads, len(timed_idx))
         sample = all_pairs[timed_idx[:n_cpu]]
@@ -688,7 +814,12 @@ def main():
         engine.release_scratch()
         del corpus
         torch.cuda.empty_cache()
-        for key, fn in (("config3", lambda: extras_config3(engine, synth, oracle, threads, torch)),
+        import tempfile
+        tmpdir = tempfile.mkdtemp(prefix="acoss_bench_")
+        for key, fn in (("full_job", lambda: extras_full_job(corpus_h, torch, tmpdir)),
+                        ("plugin_similarity", lambda: extras_plugin_similarity(corpus_h, all_pairs, oracle, threads, torch, tmpdir)),
+                        ("scatter_chain", lambda: extras_scatter_chain(engine, oracle, torch)),
+                        ("config3", lambda: extras_config3(engine, synth, oracle, threads, torch)),
                         ("early_snf", lambda: extras_early_snf(engine, synth, torch)),
                         ("ftm2d", lambda: extras_ftm2d(engine, torch)),
                         ("scatter_csm", lambda: extras_scatter_csm(engine, oracle, torch))):

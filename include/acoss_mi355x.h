@@ -390,7 +390,10 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
  * owns that device memory until acoss_corpus_destroy.  acoss_corpus_wrap builds the same handle around arrays the
  * caller already holds on the DEVICE (f32 / n32: the corpus minus its mean, times a power of two, rounded to float32,
  * and its squared norms; norms_scaled: those norms in float64 on the HOST; all three NULL: float64 kernels only); the
- * caller keeps ownership.  One call at a time per handle (it owns the pinned staging of acoss_serra09_scores). */
+ * caller keeps ownership.  Thread safety: acoss_serra09_scores calls on ONE handle are serialised inside the library (a
+ * per-handle mutex: the handle owns the call's pinned staging); calls on different handles, each with its own scratch
+ * and stream, run concurrently.  The environment switch ACOSS_SCORER_F64 (non-empty, not "0": float64 kernels only) is
+ * read once, when the handle is made. */
 typedef struct acoss_corpus acoss_corpus;
 int acoss_corpus_create(const double *feats, const int64_t *frame_off, int n_songs, int d, const double *gchroma,
                         int nbins, acoss_corpus **out);

@@ -1,0 +1,85 @@
+"""BASELINE config 2 ("MAP vs ref" of BASELINE.json:metric) and the plugin driver against fixtures the reference itself
+produced (tests/golden/make_golden_config2.py): every score of the 64-song slice of the headline corpus and the
+reference's evaluation statistics; the six score vectors of the reference's own Serra09.similarity; and the float32
+scattering-feature chain (Serra09.py:186-192) at its real feature width."""
+import zlib
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_config2_slice_all_pairwise_scores_and_map_equal_reference(golden, tmp_path, monkeypatch):
+    """Serra09.all_pairwise on the first 64 songs of synth.config2() (1000 frames each): all 2 016 chroma_qmax and
+    chroma_dmax scores and (MR, MRR, MDR, MAP, Top-k) array_equal the reference's (CoverAlgorithm.py:138-184,
+    330-418), with the ranks from the host argsort form and from the GPU."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    monkeypatch.chdir(tmp_path)
+    g = golden("config2_slice64")
+    n = int(g["n_songs"])
+    corpus = synth.make_corpus(n // 4, 4, n_frames=1000, seed=20260)
+    assert zlib.crc32(corpus.feats.tobytes()) == int(g["corpus_crc"][0])     # same inputs as the reference saw
+    alg = Serra09(corpus, shortname="config2slice", do_memmaps=True, cachedir=str(tmp_path / "cache"))
+    alg.all_pairwise(symmetric=True)
+    pairs = synth.all_pairs(n)
+    for key in ("chroma_qmax", "chroma_dmax"):
+        got = np.asarray(alg.Ds[key])[pairs[:, 0], pairs[:, 1]]
+        assert np.array_equal(got, g[key].astype(np.float32)), key
+    for key, want in (("chroma_qmax", g["stats_qmax"]), ("chroma_dmax", g["stats_dmax"])):
+        for on_gpu in (False, True):
+            MR, MRR, MDR, MAP, tops = alg.getEvalStatistics(key, verbose=False, write_csv=False, on_gpu=on_gpu)
+            assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), want), (key, on_gpu)
+    alg.cleanup_memmap()
+
+
+def test_plugin_similarity_equals_the_references_own_similarity(golden, tmp_path):
+    """The dict Serra09.similarity returns (chroma with OTI, MFCC without, float32 'ssms' features without window:
+    Serra09.py:158-196) against what the reference's own Serra09.similarity returned on the same features."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    g = golden("serra09_similarity_ref")
+    off, so = g["frame_off"], g["ssms_off"]
+    corpus = synth.Corpus(g["feats"], off, g["gchroma"], [str(x) for x in g["labels"]])
+    corpus.mfcc = [np.ascontiguousarray(g["mfcc"][off[i]:off[i + 1]].T) for i in range(corpus.n_songs)]
+    corpus.ssms = [np.ascontiguousarray(g["ssms"][so[i]:so[i + 1]]) for i in range(corpus.n_songs)]
+    alg = Serra09(corpus, shortname="simref", do_memmaps=False, cachedir=str(tmp_path / "cache"))
+    sims = alg.similarity(g["pairs"].astype(np.int64))
+    for key in ("chroma_qmax", "chroma_dmax", "mfcc_qmax", "mfcc_dmax"):
+        assert np.array_equal(sims[key], g[key]), key
+    # float32 CSM: the reference's goes through BLAS sgemm, ours through v_mfma_f32; the fixture's pairs are the ones
+    # whose masks do not depend on that summation order (ssms_robust)
+    ok = g["ssms_robust"]
+    assert ok.sum() >= 20
+    for key in ("ssms_scatter_qmax", "ssms_scatter_dmax"):
+        assert np.array_equal(sims[key][ok], g[key][ok]), key
+
+
+def test_scattering_feature_chain_at_full_width(orc):
+    """Serra09.py:186-192 at the real feature width: float32 (n - m + 1) x 20 736 features -> get_csm on the float32
+    matrix cores -> mutual mask without window -> qmax / dmax, against the oracle's float32 get_csm + its mask and
+    alignment.  Smooth features (a random walk along time), so that distances spread over orders of magnitude and no
+    mask bit hangs on the float32 summation order: checked per pair against the oracle's float64 CSM."""
+    from acoss_amd import engine
+    engine.require_gpu()
+    rng = np.random.default_rng(77)
+    D, lens = 20736, [150, 131, 172]
+    ss = [(np.cumsum(rng.standard_normal((n, D)), axis=0) / 8.0).astype(np.float32) for n in lens]
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    corpus = engine.DeviceCorpus(np.concatenate(ss), off)
+    pairs = np.array([(0, 1), (1, 2), (2, 0), (1, 1)], dtype=np.int32)
+    got = engine.serra09_scores(corpus, pairs, m=1, kappa=0.095, do_oti=False)
+    checked = 0
+    for t, (i, j) in enumerate(pairs):
+        B32 = orc.csm_to_binary_mutual(orc.get_csm(ss[i], ss[j]), 0.095)
+        B64 = orc.csm_to_binary_mutual(orc.get_csm(ss[i].astype(np.float64), ss[j].astype(np.float64)), 0.095)
+        if not np.array_equal(B32, B64):
+            continue                                  # a bit that depends on float32 rounding: not a parity case
+        M, N = B32.shape
+        Dm = np.zeros(M * N, dtype=np.float32)
+        q = orc.qmax(np.ascontiguousarray(B32.flatten()), Dm, M, N) / (M + N)
+        d = orc.dmax(np.ascontiguousarray(B32.flatten()), Dm, M, N) / (M + N)
+        assert got["qmax"][t] == q and got["dmax"][t] == d, (t, got["qmax"][t], q, got["dmax"][t], d)
+        checked += 1
+    assert checked >= 3

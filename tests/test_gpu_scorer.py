@@ -107,3 +107,54 @@ def test_scorer_other_widths_windows_and_errors(lib, orc):
     one = np.zeros(1)
     assert lib.acoss_serra09_scores(h, pairs.ctypes.data, 1, 5, 0.1, 1, 1, 0, None, 0, one.ctypes.data, None, None, None) == -22
     lib.acoss_corpus_destroy(h)
+
+
+def test_scorer_handles_run_concurrently_and_one_handle_serialises(lib, orc):
+    """Thread safety as include/acoss_mi355x.h states it: two handles, each with its own scratch and stream, scored from
+    two host threads at once give the results of the sequential calls; two threads calling on ONE handle are serialised
+    by its mutex (they share its pinned staging) and both get correct scores."""
+    import threading
+    import torch
+    from acoss_amd import synth
+    corpora = [synth.make_corpus(6, 3, seed=s, lengths=lambda r: int(r.integers(200, 640))) for s in (41, 42)]
+    rng = np.random.default_rng(5)
+    plists = []
+    for ch in corpora:
+        allp = synth.all_pairs(ch.n_songs)
+        plists.append(np.ascontiguousarray(allp[rng.permutation(len(allp))[:120]], dtype=np.int32))
+    expect = [orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, p, nthreads=8)[:2] for ch, p in zip(corpora, plists)]
+    handles, scratch, streams = [], [], []
+    for ch, p in zip(corpora, plists):
+        h = ctypes.c_void_p()
+        fo = np.ascontiguousarray(ch.frame_off, dtype=np.int64)
+        assert lib.acoss_corpus_create(ch.feats.ctypes.data, fo.ctypes.data, ch.n_songs, 12, ch.gchroma.ctypes.data, 12, ctypes.byref(h)) == 0
+        need = lib.acoss_serra09_scratch_bytes(h, p.ctypes.data, len(p), 9, 40)
+        handles.append(h)
+        scratch.append([torch.empty(need, dtype=torch.uint8, device="cuda") for _ in range(2)])
+        streams.append(torch.cuda.Stream())
+    results = {}
+
+    def call(tag, which, buf, stream_ptr):
+        p = plists[which]
+        q, d = np.full(len(p), np.nan), np.full(len(p), np.nan)
+        for _ in range(3):
+            rc = lib.acoss_serra09_scores(handles[which], p.ctypes.data, len(p), 9, 0.095, 1, 3, 40, ctypes.c_void_p(buf.data_ptr()),
+                                          buf.numel(), q.ctypes.data, d.ctypes.data, None, ctypes.c_void_p(stream_ptr))
+            assert rc == 0, lib.acoss_last_error()
+        results[tag] = (q, d)
+
+    try:
+        threads = [threading.Thread(target=call, args=("a", 0, scratch[0][0], streams[0].cuda_stream)),
+                   threading.Thread(target=call, args=("b", 1, scratch[1][0], streams[1].cuda_stream)),
+                   threading.Thread(target=call, args=("a2", 0, scratch[0][1], streams[1].cuda_stream))]     # same handle as "a"
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        torch.cuda.synchronize()
+        for tag, which in (("a", 0), ("b", 1), ("a2", 0)):
+            assert np.array_equal(results[tag][0], expect[which][0]), tag
+            assert np.array_equal(results[tag][1], expect[which][1]), tag
+    finally:
+        for h in handles:
+            lib.acoss_corpus_destroy(h)

@@ -209,3 +209,52 @@ def test_snf_oracle_against_reference(golden):
     np.testing.assert_allclose(keep["fused"], g["c0_fused"], rtol=0, atol=1e-11)
     assert np.array_equal(keep["B"], g["c0_B"])
     assert np.array_equal(np.array(q), g["c_snf_qmax"]) and np.array_equal(np.array(d), g["c_snf_dmax"])
+
+
+def test_config2_slice_scores_and_map(orc, golden):
+    """BASELINE config 2 (1000-frame songs): a sample of the 2 016 reference scores of the 64-song slice through the
+    oracle, and the oracle's evaluation statistics on the reference's full slice score matrix (the -m gpu test runs
+    all 2 016 pairs through the plugin)."""
+    import zlib
+    from acoss_amd import synth
+    from oracle.evalstats import get_eval_statistics
+    g = golden("config2_slice64")
+    n = int(g["n_songs"])
+    corpus = synth.make_corpus(n // 4, 4, n_frames=1000, seed=20260)
+    assert zlib.crc32(corpus.feats.tobytes()) == int(g["corpus_crc"][0])
+    pairs = synth.all_pairs(n)
+    pick = np.r_[0:6, 40:44, np.arange(100, len(pairs), 97)]            # in-clique and cross-clique pairs
+    q, d, _ = orc.serra09_pairs(corpus.feats, corpus.frame_off, corpus.gchroma, pairs[pick], nthreads=8)
+    assert np.array_equal(q, g["chroma_qmax"][pick]) and np.array_equal(d, g["chroma_dmax"][pick])
+    for key in ("qmax", "dmax"):
+        D = np.zeros((n, n), dtype=np.float32)
+        D[pairs[:, 0], pairs[:, 1]] = g["chroma_" + key]
+        D += D.T
+        MR, MRR, MDR, MAP, tops = get_eval_statistics(D, corpus.cliques())
+        assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["stats_" + key])
+
+
+def test_reference_similarity_fixture(orc, golden):
+    """The six score vectors the reference's own Serra09.similarity returned (make_golden_config2.py --similarity)
+    against the oracle: chroma and MFCC chains exactly; the float32 'ssms' chain (get_csm in float32, no window,
+    Serra09.py:186-192) on the pairs whose masks do not depend on the float32 summation order."""
+    g = golden("serra09_similarity_ref")
+    feats, off, gc, pairs = g["feats"], g["frame_off"], g["gchroma"], g["pairs"]
+    q, d, _ = orc.serra09_pairs(feats, off, gc, pairs, nthreads=4)
+    assert np.array_equal(q, g["chroma_qmax"]) and np.array_equal(d, g["chroma_dmax"])
+    mf, so, ss = g["mfcc"], g["ssms_off"], g["ssms"]
+    for t, (i, j) in enumerate(pairs):
+        a, b = mf[off[i]:off[i + 1]], mf[off[j]:off[j + 1]]
+        S = orc.sliding_csm(orc.get_csm(a, b), 9)                       # float32 CSM, float64 window sums (:178-179)
+        B = orc.csm_to_binary_mutual(S, 0.095)
+        M, N = B.shape
+        D = np.zeros(M * N, dtype=np.float32)
+        assert orc.qmax(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N) == g["mfcc_qmax"][t]
+        assert orc.dmax(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N) == g["mfcc_dmax"][t]
+        if not g["ssms_robust"][t]:
+            continue
+        B = orc.csm_to_binary_mutual(orc.get_csm(ss[so[i]:so[i + 1]], ss[so[j]:so[j + 1]]), 0.095)
+        M, N = B.shape
+        D = np.zeros(M * N, dtype=np.float32)
+        assert orc.qmax(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N) == g["ssms_scatter_qmax"][t]
+        assert orc.dmax(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N) == g["ssms_scatter_dmax"][t]
