@@ -19,6 +19,7 @@
 #include "common.h"
 #include "kernel_utils.h"
 
+#include <stdlib.h>
 #include <type_traits>
 
 namespace acoss {
@@ -187,6 +188,216 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
     if (n_steps > 1) step(n_steps - 1, std::true_type{});
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same computation turned by 90 degrees (round 3): x stationary, y streaming.  A block owns a BAND of 56 output rows
+// of one pair (64 C rows: the window's 8-row halo is recomputed per band, the same 14 % the column strips recompute) and
+// walks RIGHT over the columns in chunks of 128 C columns; the last 15 columns of a chunk are carried to the next one
+// inside LDS.  Why: the column-strip kernel stores 448-byte row pieces at a 4 KB pitch (5.1 TB/s as a pure store pattern,
+// tools/ubench/plane_layout.hip); here every wave instruction stores 512 contiguous, line-aligned bytes of ONE row and the
+// next chunk continues that row (5.8 TB/s), and -- what the column strips cannot do at all without halving their store
+// rate -- the same rows can leave as two 16-bit planes of 256-byte pieces (5.6 TB/s) for the selection kernels to read
+// at 2 bytes per cell.
+//
+// Per chunk: C[64][128] on the matrix cores into LDS (wave w: columns 16w .. 16w+15, four 16-row tiles; the y fragments
+// of the next chunk are already in flight), LDS-only barrier, then wave w forms rows 7w .. 7w+6 of the band: a lane walks
+// two adjacent diagonals down 7 rows (15 aligned 8-byte LDS reads for 14 outputs), every output summed in the order
+// k = 0..8 -- the arithmetic of crp_strip32_kernel cell for cell (tests/test_gpu_fast_path.py pins both against the host
+// emulation).  Walking diagonals, the columns a lane holds drift by one per row, so row q of a chunk covers columns
+// [A + q, A + q + 128) with A = 128 t - 15 (+ 1 in odd waves: 8-byte alignment of the diagonal reads).  Stores must be
+// line-aligned (the same pieces shifted by a few cells store at half the rate), so each row is brought into place in
+// registers: the aligned block [128 (t-1), 128 t) of a row is the tail of what the previous chunk produced (kept in two
+// registers per row) followed by the first few lanes of the current chunk's -- one select and one ds_bpermute per
+// value -- and is stored one chunk late; a last pass without arithmetic flushes the final block.
+constexpr int R32_BR = 56;              // output rows per band
+constexpr int R32_CR = R32_BR + S32_HALO;     // C rows per band (64 = four matrix-core tiles)
+constexpr int R32_CW = 128;             // C columns per chunk
+constexpr int R32_CARRY = 15;           // C columns carried from chunk to chunk
+constexpr int R32_LD = 147;             // odd (the diagonal stride LD + 1 keeps 8-byte alignment); >= CARRY + CW
+constexpr int R32_RPW = R32_BR / 8;     // output rows per wave
+#ifndef R32_WPS
+#define R32_WPS 6                       // waves per SIMD the register allocation aims at: three blocks per CU (42 KB of LDS each)
+#endif
+
+// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes), 2 = no stores (development probe)
+template <int D, int OUT = 0>
+__global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *__restrict__ xp, int max_nx,
+                                                         const float *__restrict__ feats, const float *__restrict__ norms,
+                                                         const acoss_pair_desc *__restrict__ descs, int bands,
+                                                         uint32_t *__restrict__ out)
+{
+    constexpr int KSTEPS = (D + 3) / 4;
+    __shared__ __attribute__((aligned(16))) float cbuf_raw[R32_CR * R32_LD + 2 * S32_CPAD + 1];
+    // the band's x frames as matrix-core operands: row r, lane group lk -> the four floats [bin lk, bin 4 + lk, bin 8 + lk,
+    // bin 12 + lk] (one 16-byte read per tile hands a lane its operand of every contraction step), and their squared norms
+    __shared__ __attribute__((aligned(16))) float xa[R32_CR * 16];
+    __shared__ __attribute__((aligned(16))) float xn[R32_CR];
+    float *const cbuf = cbuf_raw + S32_CPAD;
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / bands;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - S32_WIN + 1, N = ds.ny - S32_WIN + 1;
+    const int R0 = (lb % bands) * R32_BR;
+    if (R0 >= M) return;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, lk = lane >> 4;
+    if ((int64_t)4 * ((int64_t)M + 64) * ds.crp_pitch > 0x7fffffffLL) return;      // 32-bit offsets, see strip_offsets_fit()
+    // the band's 64 x frames (rotated by the OTI, 16 floats each: D bins, the norm, zeros): 256 chunks of 16 bytes
+    if (tid < R32_CR * (S32_XP / 4)) {
+        const float *xsrc = xp + (int64_t)p * max_nx * S32_XP;
+        const int r = tid >> 2, c = tid & 3;
+        const int row = min(R0 + r, ds.nx - 1);
+        const float4 v = reinterpret_cast<const float4 *>(xsrc)[row * (S32_XP / 4) + c];
+        const float e4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = 4 * c + i;              // position in the packed line; (e & 3) == i
+            if (e == D) xn[r] = e4[i];
+            xa[r * 16 + i * 4 + c] = e < D ? e4[i] : 0.0f;      // bin e = 4 c + i: group i, step c
+        }
+    }
+    // chunks: until every output column (< ny - 8) has left the lanes that hold real sums: a row's last block takes its
+    // final 15 - q columns from lanes that only a further chunk fills (its y frames are clamped copies, never summed into
+    // a stored cell)
+    const int n_chunks = (ds.ny + S32_HALO - 1 + R32_CW - 1) / R32_CW;
+    // y fragments of chunk t for this wave's 16 columns
+    auto load_y = [&](const int t, float (&bf)[KSTEPS], float &yy) {
+        const int jc = min(t * R32_CW + 16 * wave + lr, ds.ny - 1);
+        const float *yp = feats + (ds.y_row0 + jc) * D;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) {
+            const int bin = 4 * s + lk;
+            bf[s] = bin < D ? yp[min(bin, D - 1)] : 0.0f;
+        }
+        yy = norms[ds.y_row0 + jc];
+    };
+    float bcur[KSTEPS], bnext[KSTEPS], ycur, ynext = 0.0f;
+    load_y(0, bcur, ycur);
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) bnext[s] = 0.0f;
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(out) + 4 * ds.crp_off, 0, (int)(4 * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
+    const bool even_layout = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);       // block-uniform: 8-byte stores
+    const int bw = wave & 1;                 // odd waves sit one column to the right (see above)
+    float *const wr = cbuf + (4 * lk) * R32_LD + R32_CARRY + 16 * wave + lr;
+    const float *const rdd = cbuf + (wave * R32_RPW) * R32_LD + bw + 2 * lane;
+    const v4f32 *const xa_rd = reinterpret_cast<const v4f32 *>(xa) + lr * 4 + lk;         // + 64 per row tile
+    const v4f32 *const xn_rd = reinterpret_cast<const v4f32 *>(xn) + lk;                  // + 4 per row tile
+    // carry: columns [128, 143) of all 64 rows -> [0, 15): 960 floats, two per thread for the first 480 threads
+    const int ce0 = 2 * tid, ce1 = 2 * tid + 1;
+    const int cr0 = ce0 / R32_CARRY, cc0 = ce0 - cr0 * R32_CARRY, cr1 = ce1 / R32_CARRY, cc1 = ce1 - cr1 * R32_CARRY;
+    const bool carrier = tid < R32_CR * R32_CARRY / 2;
+    float pa[R32_RPW], pb[R32_RPW];          // the previous chunk's sums of this lane, per row
+#pragma unroll
+    for (int q = 0; q < R32_RPW; q++) pa[q] = pb[q] = 0.0f;
+
+    // block [128 (t-1), 128 t) of row q: previous chunk's lanes [sh, 64) then the current chunk's lanes [0, sh).
+    // FAST (block-uniform): whole band inside the matrix, even layout, block inside the row: one unconditional 8-byte store.
+    // BW = the wave's parity (compile-time here: which of a lane's two sums opens an aligned pair depends on it).
+    // Keys are the bit patterns of the sums (>= +0) with the sign bit set: -|s|.
+    auto emit = [&](const int t, const int q, const float ca, const float cb, auto fast_tag, auto bw_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int BW = decltype(bw_tag)::value;
+        const int sigma = R32_CARRY - BW - q;          // cells between the block's first column and the lane pair that holds it
+        const bool odd = (sigma & 1) != 0;
+        const int sh0 = sigma >> 1, sh1 = (sigma + 1) >> 1;
+        const float c0 = odd ? cb : ca, p0 = odd ? pb[q] : pa[q];
+        const float c1 = odd ? ca : cb, p1 = odd ? pa[q] : pb[q];
+        const float x0 = lane < sh0 ? -fabsf(c0) : -fabsf(p0), x1 = lane < sh1 ? -fabsf(c1) : -fabsf(p1);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh0) & 63) << 2, (int)__float_as_uint(x0));
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh1) & 63) << 2, (int)__float_as_uint(x1));
+        const int gi = R0 + wave * R32_RPW + q;
+        const int soff = 4 * (gi * ds.crp_pitch + (t - 1) * R32_CW);
+        if (OUT == 2) {
+            if (r0 == 0x12345u) __builtin_amdgcn_raw_buffer_store_b32(r1, orsrc, 4 * (lane & 63), 0, 0);
+        } else if (FAST) {
+            __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){r0, r1}, orsrc, 8 * lane, soff, S32_STORE_POLICY);
+        } else if (gi < M) {
+            const int col = (t - 1) * R32_CW + 2 * lane;
+            if (col < N) __builtin_amdgcn_raw_buffer_store_b32(r0, orsrc, 8 * lane, soff, S32_STORE_POLICY);
+            if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(r1, orsrc, 8 * lane + 4, soff, S32_STORE_POLICY);
+        }
+    };
+    const bool fast_band = even_layout && (R0 + R32_BR <= M);      // block-uniform
+
+    auto chunk = [&](const int t, auto fast_tag, auto bw_tag) {
+        if (t + 1 < n_chunks) load_y(t + 1, bnext, ynext);
+        // ---- C rows [R0, R0 + 64) x columns [128 t, 128 t + 128): this wave's 16 columns, two row tiles at a time: the LDS
+        // operands of a half are requested before the first is used (left to itself under the 80-register budget hipcc
+        // waits for every single read)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            v4f32 av[2], nv[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) av[u] = xa_rd[64 * (2 * h + u)];
+#pragma unroll
+            for (int u = 0; u < 2; u++) nv[u] = xn_rd[4 * (2 * h + u)];
+            __builtin_amdgcn_sched_barrier(0);
+            v4f32 acc[2];
+            acc[0] = (v4f32){0.f, 0.f, 0.f, 0.f};
+            acc[1] = (v4f32){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int s = 0; s < KSTEPS; s++) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][s], bcur[s], acc[u], 0, 0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+#pragma unroll
+                for (int r = 0; r < 4; r++)
+                    wr[(16 * (2 * h + u) + r) * R32_LD] = fmaxf(fmaf(-2.0f, acc[u][r], nv[u][r] + ycur), 0.0f);
+            }
+        }
+        lds_barrier();
+        // ---- rows 7w .. 7w+6 of the band: window sums along the lane's two diagonals
+        v2f32 v[R32_RPW + S32_HALO];
+#pragma unroll
+        for (int m = 0; m < R32_RPW + S32_HALO; m++) v[m] = *reinterpret_cast<const v2f32 *>(rdd + m * (R32_LD + 1));
+        // carry the chunk's last 15 columns: read before the barrier, write after it
+        float k0 = 0.f, k1 = 0.f;
+        if (carrier) {
+            k0 = cbuf[cr0 * R32_LD + R32_CW + cc0];
+            k1 = cbuf[cr1 * R32_LD + R32_CW + cc1];
+        }
+#pragma unroll
+        for (int q = 0; q < R32_RPW; q++) {
+            v2f32 s = v[q];
+#pragma unroll
+            for (int k = 1; k < S32_WIN; k++) s += v[q + k];
+            if (t > 0) emit(t, q, s.x, s.y, fast_tag, bw_tag);
+            pa[q] = s.x;
+            pb[q] = s.y;
+        }
+        lds_barrier();
+        if (carrier) {
+            cbuf[cr0 * R32_LD + cc0] = k0;
+            cbuf[cr1 * R32_LD + cc1] = k1;
+        }
+#pragma unroll
+        for (int s = 0; s < KSTEPS; s++) bcur[s] = bnext[s];
+        ycur = ynext;
+    };
+    // blocks [128 (t-1), 128 t) that lie inside the row take the unconditional stores
+    const int t_fast = fast_band ? min(N / R32_CW, n_chunks - 1) : 0;
+    if (bw) {
+        int t = 0;
+        for (; t <= t_fast; t++) chunk(t, std::true_type{}, std::integral_constant<int, 1>{});
+        for (; t < n_chunks; t++) chunk(t, std::false_type{}, std::integral_constant<int, 1>{});
+#pragma unroll
+        for (int q = 0; q < R32_RPW; q++) emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 1>{});
+    } else {
+        int t = 0;
+        for (; t <= t_fast; t++) chunk(t, std::true_type{}, std::integral_constant<int, 0>{});
+        for (; t < n_chunks; t++) chunk(t, std::false_type{}, std::integral_constant<int, 0>{});
+#pragma unroll
+        for (int q = 0; q < R32_RPW; q++) emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 0>{});
+    }
+}
+
 }  // namespace acoss
 
 using namespace acoss;
@@ -204,6 +415,21 @@ extern "C" int acoss_crp_planar32_batch(const float *xp, const float *feats, con
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
+    // ACOSS_STRIP32_FORM=cols: the column-strip kernel of round 2 (A/B comparisons); default: row bands
+    const char *form_env = getenv("ACOSS_STRIP32_FORM");
+    const bool form_rows = !(form_env && form_env[0] == 'c');
+    if (form_rows) {
+        const int bands = ceil_div(max_nx - win + 1, R32_BR);
+        if ((int64_t)K * bands > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
+        const unsigned nb = (unsigned)((int64_t)K * bands);
+        hipStream_t st2 = (hipStream_t)stream;
+#ifdef ACOSS_PROBES
+        if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_rows32_kernel<12, 2>), dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out); return launch_check("crp_rows32_kernel probe"); }
+#endif
+        if (d == 12) hipLaunchKernelGGL(crp_rows32_kernel<12>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out);
+        else hipLaunchKernelGGL(crp_rows32_kernel<13>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out);
+        return launch_check("crp_rows32_kernel");
+    }
     const int strips = ceil_div(max_ny - win + 1, S32_TN);
     if ((int64_t)K * strips > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
     const unsigned blocks = (unsigned)((int64_t)K * strips);

@@ -29,6 +29,28 @@ def test_shards_partition_the_pair_list_and_balance_cost():
         assert loads.max() / loads.mean() < 1.01                        # ragged lengths balance
 
 
+def test_world8_shards_balance_on_the_config3_length_distribution():
+    """World size 8 (one node of MI355X) on the DA-TACOS-shaped length distribution of BASELINE config 3
+    (synth.config3: lengths ~N(520, 120) clipped to [200, 1200]; here 5 000 songs = 12.5 M pairs of the 15 000):
+    the eight shards partition the pair list, their sizes differ by at most one and their costs by under 1 %."""
+    rng = np.random.default_rng(15000)
+    lens = np.clip(rng.normal(520, 120, size=5000), 200, 1200).astype(np.int64)
+    off = np.concatenate([[0], np.cumsum(lens)])
+    pairs = synth.all_pairs(len(lens))
+    costs = sharding.pair_costs(off, pairs, win=9)
+    owner = np.full(len(pairs), -1, dtype=np.int8)
+    loads, sizes = [], []
+    for r in range(8):
+        idx = sharding.shard_indices(costs, 8, r)
+        assert np.all(owner[idx] == -1)
+        owner[idx] = r
+        loads.append(float(costs[idx].sum()))
+        sizes.append(len(idx))
+    assert np.all(owner >= 0)                                               # a partition
+    assert max(sizes) - min(sizes) <= 1
+    assert max(loads) / min(loads) <= 1.01
+
+
 def test_scatter_to_matrix_symmetrises_like_the_reference():
     pairs = synth.all_pairs(5)
     scores = np.arange(1, len(pairs) + 1, dtype=np.float64)
@@ -62,7 +84,7 @@ def _worker(rank, world, port, K, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,K", [(2, 101), (3, 64), (2, 1)])
+@pytest.mark.parametrize("world,K", [(2, 101), (3, 64), (2, 1), (8, 1003)])
 def test_gather_scores_gloo(tmp_path, world, K):
     port = _free_port()
     mp.spawn(_worker, args=(world, port, K, str(tmp_path)), nprocs=world, join=True)
