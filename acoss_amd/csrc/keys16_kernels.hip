@@ -1,0 +1,374 @@
+// keys16_kernels.hip -- row and column kNN selection on the 16-bit key plane (keys16.h) and the float64 refinement of
+// what neither the 16-bit keys nor recomputed float32 values can decide.  Outputs: the row / column bit planes of
+// ThreshWork (thresh_work.h), which combine_bits_kernel (crp_kernels.hip) turns into the bit-packed mutual mask --
+// the same planes, bit for bit, as select_rows_planar_kernel / select_cols_planar_kernel leave.
+//
+// Data layout in registers: a lane owns 16 CONSECUTIVE positions of its row (column), two keys per register.  A row is then
+// read with two 16-byte loads per lane (2 KB per wave, contiguous), the lane's 16 mask bits are exactly one uint16 of the
+// row's bit vector (no ballots, no lane transposition: 128 contiguous bytes per row leave the wave), and the per-key work
+// runs on packed 16-bit instructions.
+#include "keys16.h"
+
+#include <stdlib.h>
+
+namespace acoss {
+
+__device__ __attribute__((aligned(32))) const uint32_t k16_pad_block[8] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu,
+                                                                            0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+
+// positions >= n of a lane's 16 -> K16_PAD (lanes that straddle the end of the row only)
+__device__ inline void k16_pad_tail(u16x2 (&h)[8], int n, int lane)
+{
+    const int nv = n - 16 * lane;          // valid positions of this lane
+    if (nv >= 16) return;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        if (2 * v >= nv) h[v] = k16_splat(K16_PAD);
+        else if (2 * v + 1 >= nv) h[v].y = (unsigned short)K16_PAD;
+    }
+}
+
+// the keys a wave could not decide: 2 KB to a side-buffer slot, position order
+__device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, int p, int dir, int which, unsigned th, int lane)
+{
+    if (w.side_keys == nullptr) return false;
+    int slot = 0;
+    if (lane == 0) slot = atomicAdd(w.side_counter, 1);
+    slot = __builtin_amdgcn_readfirstlane(slot);
+    if (slot >= w.side_cap) return false;
+    uint4 *dst = reinterpret_cast<uint4 *>(w.side_keys + (int64_t)slot * 1024) + 2 * lane;
+    dst[0] = make_uint4(k16_to_u32(h[0]), k16_to_u32(h[1]), k16_to_u32(h[2]), k16_to_u32(h[3]));
+    dst[1] = make_uint4(k16_to_u32(h[4]), k16_to_u32(h[5]), k16_to_u32(h[6]), k16_to_u32(h[7]));
+    if (lane == 0) w.side_slots[slot] = make_int4(p, dir, which, (int)th);
+    return true;
+}
+
+constexpr int K16_ROWS_PER_WAVE = 16;
+
+// ---- rows ------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(256, 8) void select_rows_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int rows_blocks, K16Ctx cx)
+{
+    __shared__ __attribute__((aligned(16))) unsigned hist_all[4 * K16_HIST_WORDS];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / rows_blocks;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r0 = ((lb % rows_blocks) * 4 + wave) * K16_ROWS_PER_WAVE;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (r0 >= M) return;
+    const int r1 = min(r0 + K16_ROWS_PER_WAVE, M);
+    const int lane = threadIdx.x & 63;
+    const int k = knn_count(k_mode, kv, N);
+    unsigned *hist = hist_all + wave * K16_HIST_WORDS;
+    hist256_clear(hist, lane);
+    hist[HIST256_BINS + 64 + 192 + lane] = 0u;
+    HistWarm warm{0, K16_SHIFT0};
+    const unsigned koff = cx.koff[p];
+    const float *pair_band = w.band + 2 * p;
+    // lane l reads bytes [32 l, 32 l + 32) of the row; lanes past the end read a block of padding keys instead
+    const int n_lanes = (N + 15) >> 4;
+    const bool tail = (N & 15) != 0;            // wave-uniform
+    const uint16_t *base = keys + ds.crp_off + 16 * lane;
+    const bool inside = lane < n_lanes;
+    typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
+    auto row_ptr = [&](int i) {
+        return inside ? reinterpret_cast<const u32x4v *>(base + (int64_t)i * ds.crp_pitch) : reinterpret_cast<const u32x4v *>(k16_pad_block);
+    };
+    u32x4v na = __builtin_nontemporal_load(row_ptr(r0)), nb = __builtin_nontemporal_load(row_ptr(r0) + 1);
+    uint16_t *out_bits = reinterpret_cast<uint16_t *>(w.row_bits + ((int64_t)p * w.max_m) * 16);
+    for (int i = r0; i < r1; i++) {
+        u16x2 h[8] = {k16_from_u32(na.x), k16_from_u32(na.y), k16_from_u32(na.z), k16_from_u32(na.w),
+                      k16_from_u32(nb.x), k16_from_u32(nb.y), k16_from_u32(nb.z), k16_from_u32(nb.w)};
+        if (i + 1 < r1) {
+            na = __builtin_nontemporal_load(row_ptr(i + 1));
+            nb = __builtin_nontemporal_load(row_ptr(i + 1) + 1);
+        }
+        if (tail) k16_pad_tail(h, N, lane);
+        unsigned sel = 0;
+        int state = K16_DECIDED;
+        if (k <= 0) sel = 0u;
+        else if (k >= N) {
+            const int nv = N - 16 * lane;
+            sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+        } else {
+            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
+            state = s.ok ? k16_decide<D, 0>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, ds, p, i, sel) : K16_HANDOVER;
+            if (state == K16_HANDOVER) {
+                if (!k16_hand_over(h, w, p, 0, i, s.ok ? s.th : 0u, lane)) {
+                    // no room in the side buffer: marked for the strided refinement kernel
+                    if (lane == 0) {
+                        w.row_thr[(int64_t)p * w.max_m + i] = (uint64_t)(s.ok ? s.th : 0u) << 32;
+                        w.row_cut[(int64_t)p * w.max_m + i] = SELECT_UNRESOLVED;
+                    }
+                    continue;
+                }
+            }
+        }
+        if (lane == 0) w.row_cut[(int64_t)p * w.max_m + i] = state == K16_DECIDED ? 0x7fffffff : -3;
+        if (state == K16_DECIDED) out_bits[(int64_t)i * 64 + lane] = (uint16_t)sel;
+    }
+}
+
+// ---- columns ---------------------------------------------------------------------------------------------------------------
+// One 8-wave block stages 32 columns (64-byte row segments) through LDS in two halves of 512 rows; wave v then selects in
+// columns 4v .. 4v+3, each inside the window predicted by the one before.  A thread loads 8 bytes (four columns) of two
+// adjacent rows and packs them into one word per column; a wave's loads cover 16 consecutive rows.  Staged column c keeps the
+// packed rows (16 l + 2 u, 16 l + 2 u + 1) of lane l at word 33 u + (l & 31): reads (u fixed, lanes consecutive) and
+// writes (column stride 265 words = 9 banks ... 1 mod 8 with the four columns of a thread, u = 0..3 across the 32 lanes of a
+// write) are conflict-free.
+constexpr int K16_COLS = 32;
+constexpr int K16_LDC = 265;            // words per staged half column: 8 x 33 + 1
+
+template <int D>
+__global__ __launch_bounds__(512, 4) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx)
+{
+    __shared__ __attribute__((aligned(16))) unsigned colbuf[K16_COLS * K16_LDC + 8];
+    __shared__ __attribute__((aligned(16))) unsigned hist_all[8 * K16_HIST_WORDS];
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / col_blocks;
+    const int j0 = (lb % col_blocks) * K16_COLS;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (j0 >= N) return;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    u16x2 hc[4][8];
+    {
+        // thread (c2, rp): columns 4 c2 .. 4 c2 + 3 of the row pair 64 s + rp (rows 128 s + 2 rp, + 1) for s = 0..7; that pair
+        // belongs to lane 8 s + (rp >> 3) of the selecting waves, as its word u = rp & 7
+        const int c2 = threadIdx.x & 7, rp = threadIdx.x >> 3;
+        const bool fast = ((ds.crp_pitch & 3) == 0) && ((ds.crp_off & 3) == 0) && (j0 + K16_COLS <= N);      // block-uniform: 8-byte loads
+        uint2 ta[8], tb[8];
+        if (fast) {
+            const uint16_t *pb = keys + ds.crp_off + j0 + 4 * c2;
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                const int ra = min(128 * s + 2 * rp, M - 1), rb = min(128 * s + 2 * rp + 1, M - 1);
+                ta[s] = *reinterpret_cast<const uint2 *>(pb + (unsigned)(ra * ds.crp_pitch));
+                tb[s] = *reinterpret_cast<const uint2 *>(pb + (unsigned)(rb * ds.crp_pitch));
+            }
+        } else {
+            int cc = c2, rc = rp;
+            asm volatile("" : "+v"(cc), "+v"(rc));
+#pragma unroll
+            for (int s = 0; s < 8; s++) {
+                unsigned short e[2][4];
+#pragma unroll
+                for (int z = 0; z < 2; z++) {
+                    const int64_t ri = ds.crp_off + (int64_t)min(128 * s + 2 * rc + z, M - 1) * ds.crp_pitch;
+#pragma unroll
+                    for (int u = 0; u < 4; u++) e[z][u] = keys[ri + min(j0 + 4 * cc + u, N - 1)];
+                }
+                ta[s] = make_uint2((unsigned)e[0][0] | ((unsigned)e[0][1] << 16), (unsigned)e[0][2] | ((unsigned)e[0][3] << 16));
+                tb[s] = make_uint2((unsigned)e[1][0] | ((unsigned)e[1][1] << 16), (unsigned)e[1][2] | ((unsigned)e[1][3] << 16));
+            }
+        }
+        // rows past the end of the column become padding (the clamped loads above repeat the last row)
+#pragma unroll
+        for (int s = 0; s < 8; s++) {
+            if (128 * s + 2 * rp >= M) ta[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            if (128 * s + 2 * rp + 1 >= M) tb[s] = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+        }
+        unsigned *dst = colbuf + (4 * c2) * K16_LDC + 33 * (rp & 7) + (rp >> 3);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            if (half) __syncthreads();              // every wave has read the first half
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+                const int s = 4 * half + s4;        // lanes 8 s .. 8 s + 7: slots 8 s4 .. of this half
+                dst[0 * K16_LDC + 8 * s4] = (ta[s].x & 0xFFFFu) | (tb[s].x << 16);
+                dst[1 * K16_LDC + 8 * s4] = (ta[s].x >> 16) | (tb[s].x & 0xFFFF0000u);
+                dst[2 * K16_LDC + 8 * s4] = (ta[s].y & 0xFFFFu) | (tb[s].y << 16);
+                dst[3 * K16_LDC + 8 * s4] = (ta[s].y >> 16) | (tb[s].y & 0xFFFF0000u);
+            }
+            __syncthreads();
+            if ((lane >> 5) == half) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) hc[c][u] = k16_from_u32(colbuf[(4 * wave + c) * K16_LDC + 33 * u + (lane & 31)]);
+                }
+            }
+        }
+    }
+    const int ja = j0 + 4 * wave;
+    if (ja >= N) return;
+    unsigned *hist = hist_all + wave * K16_HIST_WORDS;
+    hist256_clear(hist, lane);
+    hist[HIST256_BINS + 64 + 192 + lane] = 0u;
+    const int k = knn_count(k_mode, kv, M);
+    HistWarm warm{0, K16_SHIFT0};
+    const unsigned koff = cx.koff[p];
+    const float *pair_band = w.band + 2 * p;
+    auto column = [&](const u16x2 (&h)[8], const int j) {
+        unsigned sel = 0;
+        int state = K16_DECIDED;
+#ifdef ACOSS_PROBES
+        if (cx.flags & 2) { reinterpret_cast<uint16_t *>(w.col_word(p, j, lane >> 2))[lane & 3] = (uint16_t)(h[0].x & 1); return; }
+#endif
+        if (k <= 0) sel = 0u;
+        else if (k >= M) {
+            const int nv = M - 16 * lane;
+            sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
+        } else {
+            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
+            state = s.ok ? k16_decide<D, 1>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, ds, p, j, sel) : K16_HANDOVER;
+            if (state == K16_HANDOVER) {
+                if (!k16_hand_over(h, w, p, 1, j, s.ok ? s.th : 0u, lane)) {
+                    if (lane == 0) {
+                        w.col_thr[(int64_t)p * w.max_n + j] = (uint64_t)(s.ok ? s.th : 0u) << 32;
+                        w.col_cut[(int64_t)p * w.max_n + j] = SELECT_UNRESOLVED;
+                    }
+                    return;
+                }
+            }
+        }
+        if (lane == 0) w.col_cut[(int64_t)p * w.max_n + j] = state == K16_DECIDED ? 0x7fffffff : -3;
+        // rows 16 l .. 16 l + 15 of column j = quarter (l & 3) of word l >> 2 of the column's bit vector
+        if (state == K16_DECIDED) reinterpret_cast<uint16_t *>(w.col_word(p, j, lane >> 2))[lane & 3] = (uint16_t)sel;
+    };
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+        if (ja + c < N) column(hc[c], ja + c);
+}
+
+// ---- refinement ------------------------------------------------------------------------------------------------------------
+// One wave per side-buffer slot: exact float64 values of every cell whose 16-bit key the winner's error band can reach
+// (fix_row_band; the general bit-serial selection when more than 64 cells are in reach), cells with smaller keys are selected.
+__global__ __launch_bounds__(64) void select_fix_side16_kernel(const double *__restrict__ feats, const double *__restrict__ norms, int d,
+                                                               const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
+                                                               ThreshWork w, const uint32_t *__restrict__ koff)
+{
+    __shared__ FixSmem sm;
+    const int slot = blockIdx.x;
+    if (slot >= min(*w.side_counter, w.side_cap)) return;
+    const int4 rec = w.side_slots[slot];
+    const int p = rec.x, dir = rec.y, which = rec.z;
+    const unsigned th = (unsigned)rec.w;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int len = dir ? M : N;
+    const int lane = threadIdx.x;
+    const int k = knn_count(k_mode, kv, len);
+    const uint16_t *keys = reinterpret_cast<const uint16_t *>(w.side_keys + (int64_t)slot * 1024);
+    auto key_at = [&](int q) { return (unsigned)keys[q]; };
+    uint64_t *thr = dir ? w.col_thr + (int64_t)p * w.max_n : w.row_thr + (int64_t)p * w.max_m;
+    int *cut = dir ? w.col_cut + (int64_t)p * w.max_n : w.row_cut + (int64_t)p * w.max_m;
+    unsigned h_lo, h_hi;
+    k16_reach(th, koff[p], w.band + 2 * p, h_lo, h_hi);
+    if (dir == 0) {
+        if (fix_row_band_range<0, 16>(sm, key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) return;
+        fix_row_generic_range<0, 16>(key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+    } else {
+        if (fix_row_band_range<1, 16>(sm, key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) return;
+        fix_row_generic_range<1, 16>(key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+    }
+}
+
+// rows / columns that found no room in the side buffer (never, with its 2 % capacity, on real features): the same refinement
+// from the key plane itself
+template <int DIR>
+__global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__restrict__ keys16, const double *__restrict__ feats,
+                                                            const double *__restrict__ norms, int d, const acoss_pair_desc *__restrict__ descs,
+                                                            int win, double kv, int k_mode, ThreshWork w, const uint32_t *__restrict__ koff,
+                                                            int groups, int64_t total)
+{
+    __shared__ FixSmem sm;
+    const int lane = threadIdx.x;
+    if (w.side_counter != nullptr && *w.side_counter <= w.side_cap) return;
+    for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
+        const int p = (int)(blk / groups), g = (int)(blk % groups);
+        const acoss_pair_desc ds = descs[p];
+        const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+        const int count = DIR == 0 ? M : N;
+        const int len = DIR == 0 ? N : M;
+        const int t = g * 64 + lane;
+        uint64_t *thr = (DIR == 0 ? w.row_thr + (int64_t)p * w.max_m : w.col_thr + (int64_t)p * w.max_n);
+        int *cut = (DIR == 0 ? w.row_cut + (int64_t)p * w.max_m : w.col_cut + (int64_t)p * w.max_n);
+        unsigned long long todo = __ballot(t < count && cut[t] == SELECT_UNRESOLVED);
+        if (todo == 0) continue;
+        const int k = knn_count(k_mode, kv, len);
+        while (todo) {
+            const int which = g * 64 + (__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            auto key_at = [&](int q) {
+                return (unsigned)keys16[ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which)];
+            };
+            unsigned h_lo, h_hi;
+            k16_reach((unsigned)(thr[which] >> 32), koff[p], w.band + 2 * p, h_lo, h_hi);
+            if (fix_row_band_range<DIR, 16>(sm, key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) continue;
+            fix_row_generic_range<DIR, 16>(key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
+        }
+    }
+}
+
+// defined in crp_kernels.hip
+int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st);
+
+}  // namespace acoss
+
+using namespace acoss;
+
+extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                            const float *f32, const float *n32, const double *feats, const double *norms, int d,
+                                            const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
+                                            int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
+{
+    if (!keys16 || !band || !koff || !xp || !f32 || !n32 || !feats || !norms || !descs || !bits || !work || K < 0 || max_nx < win ||
+        max_ny < win || kappa < 0.0) {
+        set_error("mask_bits_keys16_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if ((d != 12 && d != 13) || win != 9) { set_error("mask_bits_keys16_batch: supports d in {12, 13} and win == 9"); return ACOSS_ENOTSUP; }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    if (max_m > 1024 || max_n > 1024) { set_error("mask_bits_keys16_batch: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
+    if (work_bytes < thresh_work_bytes(K, max_m, max_n, true)) { set_error("mask_bits_keys16_batch: workspace too small"); return ACOSS_EINVAL; }
+    if (K == 0) return ACOSS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    w.band = band;
+    ACOSS_HIP(hipMemsetAsync(w.side_counter, 0, 256, st));
+    double kv;
+    int mode;
+    if (kappa == 0.0) { kv = 0.0; mode = 2; } else if (kappa < 1.0) { kv = kappa; mode = 0; } else { kv = kappa; mode = 1; }
+    K16Ctx cx;
+    cx.xp = xp; cx.max_nx = max_nx; cx.f32 = f32; cx.n32 = n32; cx.koff = koff;
+    cx.stats = nullptr;
+    cx.flags = 0;
+#ifdef ACOSS_PROBES
+    if (getenv("ACOSS_K16_STATS")) cx.stats = w.side_counter;
+    if (getenv("ACOSS_K16_FLAGS")) cx.flags = atoi(getenv("ACOSS_K16_FLAGS"));
+#endif
+    const int rb = ceil_div(max_m, 4 * K16_ROWS_PER_WAVE), cb = ceil_div(max_n, K16_COLS);
+    if ((int64_t)K * rb > 0x7fffffffLL || (int64_t)K * cb > 0x7fffffffLL) { set_error("mask_bits_keys16_batch: batch too large"); return ACOSS_ENOTSUP; }
+    if (d == 12) hipLaunchKernelGGL(select_rows_k16_kernel<12>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
+    else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
+    int rc = launch_check("select_rows_k16_kernel");
+    if (rc) return rc;
+    if (mutual) {
+        if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
+        else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
+        rc = launch_check("select_cols_k16_kernel");
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(select_fix_side16_kernel, dim3((unsigned)w.side_cap), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
+    rc = launch_check("select_fix_side16_kernel");
+    if (rc) return rc;
+    const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
+    hipLaunchKernelGGL(select_fix_k16_kernel<0>, dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm, (int64_t)K * gm);
+    if (mutual) hipLaunchKernelGGL(select_fix_k16_kernel<1>, dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn, (int64_t)K * gn);
+    rc = launch_check("select_fix_k16_kernel (overflow)");
+    if (rc) return rc;
+    return launch_combine_bits(descs, K, win, mutual, w, bits, st);
+}
+
+#ifdef ACOSS_PROBES
+// development: device address of the side-buffer counter block of a workspace (int[64]: [0] hand-overs, [1..3] see K16Ctx)
+extern "C" void *acoss_dev_side_counter(void *work, int K, int max_nx, int max_ny, int win)
+{
+    return thresh_work_layout(work, K, max_nx - win + 1, max_ny - win + 1, true).side_counter;
+}
+#endif

@@ -457,16 +457,17 @@ __device__ inline uint64_t shifted_plane_word(uint64_t mine, int plane_shift, in
 
 // key_at(q): the uint32 key of position q of the row / column (its source: the key matrix, or a compact copy of the row).
 // thr_hi: the high word the selection left for this row; thr / cut (may be null): where the final threshold goes.
+// (have_range: [blo, bhi] given by the caller -- the 16-bit keys of keys16.h; else derived from thr_hi and the pair's band)
 template <int DIR, int E, typename KeyAt>
-__device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
+__device__ inline void fix_row_generic_impl(KeyAt key_at, unsigned thr_hi, bool have_range, unsigned blo, unsigned bhi, const double *__restrict__ feats,
                                        const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                        const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     // the selection kernel left the high word the tied elements share: only those few need their exact value;
     // every other element is ordered by its high word alone
-    const unsigned th = thr_hi;
-    unsigned blo = 0u, bhi = 0u;
-    if (w.band != nullptr) band_limits(th, w.band + 2 * p, blo, bhi);
+    const unsigned th = have_range ? 1u : thr_hi;
+    if (!have_range && w.band != nullptr) band_limits(th, w.band + 2 * p, blo, bhi);
+    const bool banded = have_range || w.band != nullptr;
     uint64_t key[E];
     int idx[E];
 #pragma unroll
@@ -476,7 +477,7 @@ __device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const doub
         const unsigned h = key_at(q);
         uint64_t kx = (uint64_t)h << 32;
         bool exact = th == 0u || h == th;
-        if (w.band != nullptr) {
+        if (banded) {
             // approximate keys: below the band certainly selected, above it certainly not, inside it exact values decide
             kx = h < blo ? 0ull : ~0ull - 1ull;
             exact = th == 0u || (h >= blo && h <= bhi);
@@ -507,6 +508,22 @@ __device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const doub
     }
 }
 
+template <int DIR, int E, typename KeyAt>
+__device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
+                                       const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+                                       const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
+{
+    fix_row_generic_impl<DIR, E>(key_at, thr_hi, false, 0u, 0u, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane, plane_shift);
+}
+
+template <int DIR, int E, typename KeyAt>
+__device__ inline void fix_row_generic_range(KeyAt key_at, unsigned blo, unsigned bhi, const double *__restrict__ feats,
+                                             const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+                                             const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
+{
+    fix_row_generic_impl<DIR, E>(key_at, 1u, true, blo, bhi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane, 0);
+}
+
 // The same for approximate keys when few elements (<= 64) lie inside the error band, which is the rule: the wave works
 // on the band elements together.  Seven elements at a time, lane (g, kk) forms C[i + kk][j + kk] of element g with the
 // strip kernel's arithmetic (FMA chain over the rolled bins, all of a frame pair's loads in flight at once), lane g adds
@@ -522,14 +539,11 @@ struct FixSmem {
 };
 
 template <int DIR, int E, typename KeyAt>
-__device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
+__device__ inline bool fix_row_band_range(FixSmem &sm, KeyAt key_at, unsigned blo, unsigned bhi, const double *__restrict__ feats,
                                     const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                     const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
-    const unsigned th = thr_hi;
-    if (th == 0u || win != 9 || d > FIX_MAXD) return false;
-    unsigned blo, bhi;
-    band_limits(th, w.band + 2 * p, blo, bhi);
+    if (win != 9 || d > FIX_MAXD) return false;
     unsigned h[E];
     int below = 0, n = 0;
     int myidx[E];
@@ -616,6 +630,17 @@ __device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, 
     }
     __syncthreads();
     return true;
+}
+
+template <int DIR, int E, typename KeyAt>
+__device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
+                                    const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+                                    const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
+{
+    if (thr_hi == 0u) return false;
+    unsigned blo, bhi;
+    band_limits(thr_hi, w.band + 2 * p, blo, bhi);
+    return fix_row_band_range<DIR, E>(sm, key_at, blo, bhi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane, plane_shift);
 }
 
 }  // namespace acoss

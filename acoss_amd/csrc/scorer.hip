@@ -24,6 +24,7 @@ struct acoss_corpus {
     int64_t n_frames = 0;
     bool owns = false, f32_ok = false;
     bool force_f64 = false;                     // ACOSS_SCORER_F64, read once when the handle is made
+    bool keys16 = true;                         // ACOSS_SCORER_KEYS16=0: 32-bit keys for the float32 filter (round 2's form)
     std::mutex call_mutex;                      // the staging below belongs to one acoss_serra09_scores call at a time
     std::vector<int64_t> frame_off;
     std::vector<double> norms_scaled;           // squared norms of the centred, scaled frames (float64, host)
@@ -100,7 +101,7 @@ static size_t al(size_t b) { return (b + 255) & ~(size_t)255; }
 
 // device scratch of one batch of class `cls`: {descs, band, xp, T, work, bits / byte mask, C, scores}
 struct Carve {
-    size_t descs, band, xp, T, work, bits, C, scores, total;
+    size_t descs, band, koff, xp, T, work, bits, C, scores, total;
 };
 
 static Carve carve(const acoss_corpus *c, int cls, int K, int max_nx, int max_ny, int win, int64_t total_csm, int64_t total_crp)
@@ -111,6 +112,7 @@ static Carve carve(const acoss_corpus *c, int cls, int K, int max_nx, int max_ny
     const int max_m = max_nx - win + 1;
     v.descs = take(sizeof(acoss_pair_desc) * (size_t)K);
     v.band = take(2 * sizeof(float) * (size_t)K);
+    v.koff = take(sizeof(uint32_t) * (size_t)K);
     v.xp = take((cls == 3 ? 0 : (size_t)acoss_xpack_elems(K, max_nx)) * sizeof(double));
     v.T = take(((size_t)std::max<int64_t>(total_crp, 2) + 16) * (cls == 0 || cls == 1 ? 4 : 8));
     const size_t wb = cls <= 1 ? acoss_mask_bits_work_bytes(K, max_nx, max_ny, win) : acoss_binarize_work_bytes(K, max_nx, max_ny, win);
@@ -202,6 +204,8 @@ int acoss_corpus_wrap(const double *feats, const double *norms, const double *gc
     c->f32_ok = f32 && n32 && norms_scaled;
     const char *env = getenv("ACOSS_SCORER_F64");
     c->force_f64 = env && env[0] && strcmp(env, "0") != 0;
+    const char *e16 = getenv("ACOSS_SCORER_KEYS16");
+    c->keys16 = !(e16 && strcmp(e16, "0") == 0);
     if (c->f32_ok) c->norms_scaled.assign(norms_scaled, norms_scaled + c->n_frames);
     *out = c;
     return ACOSS_OK;
@@ -302,12 +306,13 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
     if (rc != ACOSS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     // pinned staging: every batch's descriptors and bands (read by asynchronous copies until the stream gets there), the scores
-    const size_t pin_descs = al(sizeof(acoss_pair_desc) * (size_t)K), pin_band = al(8 * (size_t)K), pin_scores = al(12 * (size_t)K);
-    rc = pin_reserve(c, pin_descs + pin_band + pin_scores);
+    const size_t pin_descs = al(sizeof(acoss_pair_desc) * (size_t)K), pin_band = al(8 * (size_t)K), pin_scores = al(12 * (size_t)K), pin_koff = al(4 * (size_t)K);
+    rc = pin_reserve(c, pin_descs + pin_band + pin_scores + pin_koff);
     if (rc != ACOSS_OK) return rc;
     acoss_pair_desc *h_descs = (acoss_pair_desc *)c->pin;
     float *h_band = (float *)((char *)c->pin + pin_descs);
     float *h_scores = (float *)((char *)c->pin + pin_descs + pin_band);      // [3][K] in batch order
+    uint32_t *h_koff = (uint32_t *)((char *)c->pin + pin_descs + pin_band + pin_scores);
     char *base = (char *)(((uintptr_t)scratch + 255) & ~(uintptr_t)255);
     const size_t avail = scratch_bytes - (size_t)(base - (char *)scratch);
     const int nq = (want & 1) ? 1 : 0, nd = (want & 2) ? 1 : 0, ns = (want & 4) ? 1 : 0;
@@ -344,9 +349,26 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
                 ACOSS_HIP(hipMemcpyAsync(d_band, hb, 8 * (size_t)B, hipMemcpyHostToDevice, st));
                 float *xp = (float *)(base + v.xp);
                 rc = acoss_pack_x_f32(c->f32, c->n32, c->d, d_descs, B, b.max_nx, xp, st);
-                if (!rc) rc = acoss_crp_planar32_batch(xp, c->f32, c->n32, c->d, d_descs, B, win, b.max_nx, b.max_ny, (uint32_t *)(base + v.T), st);
-                if (!rc) rc = acoss_mask_bits_planar32_batch((const uint32_t *)(base + v.T), d_band, c->feats, c->norms, c->d, d_descs, B, win, b.max_nx,
-                                                             b.max_ny, kappa, 1, bits, base + v.work, v.bits - v.work, st);
+                if (c->keys16) {
+                    // 16-bit keys (csrc/keys16.h): koff = the pattern of the float32 not below 2 W, eight octaves down
+                    uint32_t *hk = h_koff + done, *d_koff = (uint32_t *)(base + v.koff);
+                    for (int t = 0; t < B; t++) {
+                        const double w2 = 2.0 * (w[(size_t)bp[2 * (size_t)t]] + w[(size_t)bp[2 * (size_t)t + 1]]);
+                        float f = (float)w2;
+                        if ((double)f < w2) f = nextafterf(f, INFINITY);
+                        uint32_t fb;
+                        memcpy(&fb, &f, 4);
+                        hk[t] = (std::isfinite(f) && f > 7.9e-31f) ? fb - (8u << 23) : 0u;
+                    }
+                    ACOSS_HIP(hipMemcpyAsync(d_koff, hk, 4 * (size_t)B, hipMemcpyHostToDevice, st));
+                    if (!rc) rc = acoss_crp_keys16_batch(xp, c->f32, c->n32, c->d, d_descs, B, win, b.max_nx, b.max_ny, d_koff, (uint16_t *)(base + v.T), st);
+                    if (!rc) rc = acoss_mask_bits_keys16_batch((const uint16_t *)(base + v.T), d_band, d_koff, xp, c->f32, c->n32, c->feats, c->norms, c->d,
+                                                               d_descs, B, win, b.max_nx, b.max_ny, kappa, 1, bits, base + v.work, v.bits - v.work, st);
+                } else {
+                    if (!rc) rc = acoss_crp_planar32_batch(xp, c->f32, c->n32, c->d, d_descs, B, win, b.max_nx, b.max_ny, (uint32_t *)(base + v.T), st);
+                    if (!rc) rc = acoss_mask_bits_planar32_batch((const uint32_t *)(base + v.T), d_band, c->feats, c->norms, c->d, d_descs, B, win, b.max_nx,
+                                                                 b.max_ny, kappa, 1, bits, base + v.work, v.bits - v.work, st);
+                }
             } else {
                 double *xp = (double *)(base + v.xp);
                 rc = acoss_pack_x_f64(c->feats, c->norms, c->d, d_descs, B, b.max_nx, xp, st);

@@ -219,12 +219,14 @@ constexpr int R32_RPW = R32_BR / 8;     // output rows per wave
 #define R32_WPS 6                       // waves per SIMD the register allocation aims at: three blocks per CU (42 KB of LDS each)
 #endif
 
-// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes), 2 = no stores (development probe)
+// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes); 1 = the 16-bit key plane of keys16.h (2 bytes per cell: key16 =
+// min((bits -sat koff[pair]) >> 10, 0xFFFE), `out` is then a uint16 matrix with the same element indexing);
+// 2 = no stores (development probe)
 template <int D, int OUT = 0>
 __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *__restrict__ xp, int max_nx,
                                                          const float *__restrict__ feats, const float *__restrict__ norms,
                                                          const acoss_pair_desc *__restrict__ descs, int bands,
-                                                         uint32_t *__restrict__ out)
+                                                         uint32_t *__restrict__ out, const uint32_t *__restrict__ koff_of)
 {
     constexpr int KSTEPS = (D + 3) / 4;
     __shared__ __attribute__((aligned(16))) float cbuf_raw[R32_CR * R32_LD + 2 * S32_CPAD + 1];
@@ -279,9 +281,11 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     for (int s = 0; s < KSTEPS; s++) bnext[s] = 0.0f;
     __syncthreads();
 
+    constexpr int CELL = OUT == 1 ? 2 : 4;   // bytes per cell of the result
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(out) + 4 * ds.crp_off, 0, (int)(4 * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
-    const bool even_layout = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);       // block-uniform: 8-byte stores
+        reinterpret_cast<char *>(out) + CELL * ds.crp_off, 0, (int)(CELL * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
+    const bool even_layout = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);       // block-uniform: one store per lane pair
+    const uint32_t koff = OUT == 1 ? koff_of[p] : 0u;
     const int bw = wave & 1;                 // odd waves sit one column to the right (see above)
     float *const wr = cbuf + (4 * lk) * R32_LD + R32_CARRY + 16 * wave + lr;
     const float *const rdd = cbuf + (wave * R32_RPW) * R32_LD + bw + 2 * lane;
@@ -311,9 +315,19 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         const uint32_t r0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh0) & 63) << 2, (int)__float_as_uint(x0));
         const uint32_t r1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh1) & 63) << 2, (int)__float_as_uint(x1));
         const int gi = R0 + wave * R32_RPW + q;
-        const int soff = 4 * (gi * ds.crp_pitch + (t - 1) * R32_CW);
+        const int soff = CELL * (gi * ds.crp_pitch + (t - 1) * R32_CW);
         if (OUT == 2) {
             if (r0 == 0x12345u) __builtin_amdgcn_raw_buffer_store_b32(r1, orsrc, 4 * (lane & 63), 0, 0);
+        } else if (OUT == 1) {
+            const uint32_t h0 = min(__builtin_elementwise_sub_sat(r0 & 0x7fffffffu, koff) >> 10, 0xFFFEu);
+            const uint32_t h1 = min(__builtin_elementwise_sub_sat(r1 & 0x7fffffffu, koff) >> 10, 0xFFFEu);
+            if (FAST) {
+                __builtin_amdgcn_raw_buffer_store_b32(h0 | (h1 << 16), orsrc, 4 * lane, soff, S32_STORE_POLICY);
+            } else if (gi < M) {
+                const int col = (t - 1) * R32_CW + 2 * lane;
+                if (col < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h0, orsrc, 4 * lane, soff, S32_STORE_POLICY);
+                if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h1, orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
+            }
         } else if (FAST) {
             __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){r0, r1}, orsrc, 8 * lane, soff, S32_STORE_POLICY);
         } else if (gi < M) {
@@ -424,10 +438,10 @@ extern "C" int acoss_crp_planar32_batch(const float *xp, const float *feats, con
         const unsigned nb = (unsigned)((int64_t)K * bands);
         hipStream_t st2 = (hipStream_t)stream;
 #ifdef ACOSS_PROBES
-        if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_rows32_kernel<12, 2>), dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out); return launch_check("crp_rows32_kernel probe"); }
+        if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_rows32_kernel<12, 2>), dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr); return launch_check("crp_rows32_kernel probe"); }
 #endif
-        if (d == 12) hipLaunchKernelGGL(crp_rows32_kernel<12>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out);
-        else hipLaunchKernelGGL(crp_rows32_kernel<13>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out);
+        if (d == 12) hipLaunchKernelGGL(crp_rows32_kernel<12>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
+        else hipLaunchKernelGGL(crp_rows32_kernel<13>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
         return launch_check("crp_rows32_kernel");
     }
     const int strips = ceil_div(max_ny - win + 1, S32_TN);
@@ -440,4 +454,22 @@ extern "C" int acoss_crp_planar32_batch(const float *xp, const float *feats, con
     if (d == 12) hipLaunchKernelGGL(crp_strip32_kernel<12>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     else hipLaunchKernelGGL(crp_strip32_kernel<13>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
     return launch_check("crp_strip32_kernel");
+}
+
+extern "C" int acoss_crp_keys16_batch(const float *xp, const float *feats, const float *norms, int d, const acoss_pair_desc *descs,
+                                      int K, int win, int max_nx, int max_ny, const uint32_t *koff, uint16_t *out, void *stream)
+{
+    if (!xp || !feats || !norms || !descs || !koff || !out || K < 0 || max_nx < win || max_ny < win) {
+        set_error("crp_keys16_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if ((d != 12 && d != 13) || win != S32_WIN) { set_error("crp_keys16_batch: supports d in {12, 13} and win == 9"); return ACOSS_ENOTSUP; }
+    if (K == 0) return ACOSS_OK;
+    const int bands = ceil_div(max_nx - win + 1, R32_BR);
+    if ((int64_t)K * bands > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_keys16_batch: batch too large"); return ACOSS_ENOTSUP; }
+    const unsigned nb = (unsigned)((int64_t)K * bands);
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 12) hipLaunchKernelGGL((crp_rows32_kernel<12, 1>), dim3(nb), dim3(512), 0, st, xp, max_nx, feats, norms, descs, bands, reinterpret_cast<uint32_t *>(out), koff);
+    else hipLaunchKernelGGL((crp_rows32_kernel<13, 1>), dim3(nb), dim3(512), 0, st, xp, max_nx, feats, norms, descs, bands, reinterpret_cast<uint32_t *>(out), koff);
+    return launch_check("crp_rows32_kernel<keys16>");
 }

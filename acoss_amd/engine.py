@@ -334,6 +334,55 @@ def mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=True, out=None, 
     return out, work
 
 
+def keys16_koff(corpus, batch):
+    """Per pair of the batch the uint32 offset of its 16-bit keys (csrc/keys16.h): the float32 bit pattern of 2 W 2^-8, W =
+    the pair's bound on the window norm sums (song_wmax of x + of y; no windowed sum exceeds 2 W) -- key16 =
+    min((bits -sat koff) >> 10, 0xFFFE) then spans the eight octaves below 2 W with 13 mantissa bits.  The pattern is that
+    of the float32 NOT BELOW 2 W (the kernels rely on koff >= 2 W 2^-8).  Device int32 tensor (K)."""
+    w = corpus.song_wmax(batch.win)
+    sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
+    W64 = 2.0 * (w[sx] + w[sy])
+    W = W64.astype(np.float32)
+    W = np.where(W.astype(np.float64) < W64, np.nextafter(W, np.float32(np.inf)), W).astype(np.float32)
+    bits = W.view(np.uint32).astype(np.int64) - (8 << 23)
+    koff = np.where(np.isfinite(W) & (W > np.float32(2.0 ** -100)), bits, 0).astype(np.uint32)
+    return torch.from_numpy(koff.view(np.int32).copy()).to(corpus.device)
+
+
+def crp_keys16(corpus, batch, xp32, koff, out=None):
+    """crp_planar32()'s windowed sums as 16-bit keys (int16 device vector, the uint32 matrix's element indexing)."""
+    lib = _lib.load()
+    f32, n32 = float32_copy(corpus)
+    if out is None:
+        out = torch.empty(planar_elems(batch) + 64, dtype=torch.int16, device=corpus.device)
+    check(lib.acoss_crp_keys16_batch(_ptr(xp32), _ptr(f32), _ptr(n32), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win,
+                                     batch.max_nx, batch.max_ny, _ptr(koff), _ptr(out), _stream()), "crp_keys16_batch")
+    return out
+
+
+def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True, out=None, work=None):
+    """mask_bits_planar32() on the 16-bit keys of crp_keys16(): identical masks."""
+    lib = _lib.load()
+    f32, n32 = float32_copy(corpus)
+    max_m = batch.max_nx - batch.win + 1
+    if out is None:
+        out = torch.zeros(max(batch.K * max_m * bits_words(batch), 1), dtype=torch.int64, device=keys16.device)
+    need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    if work is None or work.numel() < need:
+        work = torch.empty(need, dtype=torch.uint8, device=keys16.device)
+    check(lib.acoss_mask_bits_keys16_batch(_ptr(keys16), _ptr(band), _ptr(koff), _ptr(xp32), _ptr(f32), _ptr(n32), _ptr(corpus.feats),
+                                           _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
+                                           batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out), _ptr(work), work.numel(),
+                                           _stream()), "mask_bits_keys16_batch")
+    return out, work
+
+
+def keys16_supported(corpus, batch):
+    """float64 chroma / MFCC-sized features, the reference's window, matrices up to 1024 x 1024."""
+    return (planar_supported(corpus, batch) and batch.max_nx - batch.win + 1 <= 1024 and batch.max_ny - batch.win + 1 <= 1024
+            and planar32_usable(corpus))
+
+
 def packed32(corpus):
     """The float32 copy of a float64 corpus (float32_copy) as 16-float packed frames [d values | squared norm | 0 ...]:
     the operand of the fused band kernel (mask_bits_fused); cached on the corpus."""
@@ -665,6 +714,12 @@ def release_scratch():
     torch.cuda.empty_cache()
 
 
+def keys16_default():
+    """Whether the float32 filter's keys are 16 bits wide (csrc/keys16.h: the default since round 3) or 32 (round 2's form,
+    ACOSS_KEYS16=0 / ACOSS_SCORER_KEYS16=0 for the C scorer)."""
+    return os.environ.get("ACOSS_KEYS16", "1") not in ("0", "", "false", "no")
+
+
 def planar32_default():
     """Whether the chain uses the float32-filter form of the strip kernel (crp_planar32 + mask_bits_planar32: float32 keys,
     rows and columns inside the error band refined exactly in float64: identical masks and scores) when the caller does
@@ -795,6 +850,11 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             continue
         if fused:
             bits, _ = mask_bits_fused(corpus, batch, kappa, mutual=True, out=bits_buf)
+        elif use32 and keys16_default() and keys16_supported(corpus, batch):
+            xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
+            koff = keys16_koff(corpus, batch)
+            k16 = crp_keys16(corpus, batch, xp32, koff, out=T.view(torch.int16)[:planar_elems(batch) + 64])
+            bits, work = mask_bits_keys16(k16, planar32_band(corpus, batch), koff, xp32, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
         elif use32:
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
             keys = crp_planar32(corpus, batch, xp32, out=T.view(torch.int32)[:planar_elems(batch)])

@@ -53,8 +53,9 @@ def parse():
                     help="pairs per launch batch and GPU (4096 x 3.9 MB of keys = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
     ap.add_argument("--frames", type=int, default=1000)
-    ap.add_argument("--path", choices=("fast32", "fast", "fast_f64", "fused", "staged"), default="fast32",
-                    help="fast32 (the product path): CSM + sliding window in float32 on the matrix cores, float32 keys, "
+    ap.add_argument("--path", choices=("fast16", "fast32", "fast", "fast_f64", "fused", "staged"), default="fast16",
+                    help="fast16 (the product path): fast32 with 16-bit keys -- the strip kernel writes 2 bytes per cell, the selection reads "
+                         "2, cells in reach of the error band are recomputed in float32, the rest as fast32; fast32: CSM + sliding window in float32 on the matrix cores, float32 keys, "
                          "selection with exact float64 refinement of the rows / columns inside the error band (results "
                          "identical to float64); fast: the same chain with float64 windowed sums (key high words); "
                          "fast_f64: a float64 matrix in between; fused: masks from the band kernel, no matrix in HBM "
@@ -65,7 +66,7 @@ def parse():
     return ap.parse_args()
 
 
-STAGES = {p: ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"] for p in ("fast32", "fast", "fast_f64", "fused")}
+STAGES = {p: ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"] for p in ("fast16", "fast32", "fast", "fast_f64", "fused")}
 STAGES["staged"] = ["oti", "csm", "sliding", "binarize", "qmax"]
 
 
@@ -89,18 +90,20 @@ class Runner(object):
         bits_ok = all(engine.planar_supported(corpus, b) for b in batches)
         if path in ("fast32", "fast") and not bits_ok:
             raise SystemExit("bench.py: --path %s needs float64 12 / 13-bin features and songs up to 2056 frames" % path)
+        if path == "fast16" and not all(engine.keys16_supported(corpus, b) for b in batches):
+            raise SystemExit("bench.py: --path fast16 needs float64 12 / 13-bin features and songs up to 1032 frames")
         if path == "fused" and not all(engine.fused_supported(corpus, b) for b in batches):
             raise SystemExit("bench.py: --path fused needs float64 12 / 13-bin features and songs up to 1022 frames")
-        self.planar = path in ("fast32", "fast")
+        self.planar = path in ("fast16", "fast32", "fast")
         tr = max(b.total_crp for b in batches)
         self.bits = None
-        if path in ("fast32", "fast", "fast_f64", "fused"):
+        if path in ("fast16", "fast32", "fast", "fast_f64", "fused"):
             self.bits = torch.zeros(max(b.K * (b.max_nx - m + 1) * engine.bits_words(b) for b in batches), dtype=torch.int64, device=dev)
-        if path in ("fast32", "fast", "fast_f64"):
-            s_elems = (tr // 2 + 32) if self.planar else (tr + 32)
+        if path in ("fast16", "fast32", "fast", "fast_f64"):
+            s_elems = (tr // 4 + 32) if path == "fast16" else ((tr // 2 + 32) if self.planar else (tr + 32))
             self.S = torch.empty(s_elems, dtype=torch.float64, device=dev)
             self.xp = torch.empty(max(int(lib.acoss_xpack_elems(b.K, b.max_nx)) for b in batches),
-                                  dtype=torch.float32 if path == "fast32" else corpus.feats.dtype, device=dev)
+                                  dtype=torch.float32 if path in ("fast16", "fast32") else corpus.feats.dtype, device=dev)
             need = max(int(lib.acoss_mask_bits_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
             self.work = torch.empty(need, dtype=torch.uint8, device=dev)
         elif path == "fused":
@@ -115,9 +118,12 @@ class Runner(object):
             need = max(int(lib.acoss_binarize_work_bytes(b.K, b.max_nx, b.max_ny, m)) for b in batches)
             self.work = torch.empty(need, dtype=torch.uint8, device=dev)
         self.bands = None
-        if path == "fast32":
+        self.koffs = None
+        if path in ("fast16", "fast32"):
             engine.float32_copy(corpus)
             self.bands = [engine.planar32_band(corpus, b) for b in batches]
+        if path == "fast16":
+            self.koffs = [engine.keys16_koff(corpus, b) for b in batches]
         if path == "fused":
             self.bands = [engine.planar32_band(corpus, b, fused=True) for b in batches]
         # The times of the kernels that write and read the big intermediate depend on which allocation it lives in (DESIGN.md
@@ -158,7 +164,11 @@ class Runner(object):
                 for rep in range(3):
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
-                    if path == "fast32":
+                    if path == "fast16":
+                        k16 = buf.view(torch.int16)[:engine.planar_elems(b0) + 64]
+                        engine.crp_keys16(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp), self.koffs[0], out=k16)
+                        engine.mask_bits_keys16(k16, self.bands[0], self.koffs[0], self.xp, corpus, b0, kappa, True, out=self.bits, work=self.work)
+                    elif path == "fast32":
                         engine.crp_planar32(corpus, b0, engine.pack_x32(corpus, b0, out=self.xp), out=planes)
                         engine.mask_bits_planar32(planes, self.bands[0], corpus, b0, kappa, True, out=self.bits, work=self.work)
                     else:
@@ -186,8 +196,8 @@ class Runner(object):
         ny = [b.descs["ny"].astype(np.float64) for b in batches]
         # algorithmic bytes per launch of the cross-similarity kernel of each path
         self.csm_bytes = [float(np.sum(es * (x * y + corpus.d * (x + y)))) for x, y in zip(nx, ny)]
-        cell = 4.0 if self.planar else 8.0          # keys (4 B / cell) or a float64 matrix
-        fes = 4 if path == "fast32" else es
+        cell = 2.0 if path == "fast16" else (4.0 if self.planar else 8.0)          # keys (2 or 4 B / cell) or a float64 matrix
+        fes = 4 if path in ("fast16", "fast32") else es
         self.crp_bytes = [float(np.sum(cell * (x - m + 1) * (y - m + 1) + fes * corpus.d * (x + y))) for x, y in zip(nx, ny)]
         # the fused band kernel: float32 multiply-adds of the distance products it forms (both orientations, 32 C rows
         # per 24-row band, contraction depth d + 2)
@@ -210,13 +220,16 @@ class Runner(object):
                               side_rows=self.side_rows, verify=False)
             mark(4)
             e.align_bits("qmax", self.bits, b, scores=scores_out)
-        elif self.path in ("fast32", "fast", "fast_f64"):
-            if self.path == "fast32":
+        elif self.path in ("fast16", "fast32", "fast", "fast_f64"):
+            if self.path in ("fast16", "fast32"):
                 e.pack_x32(self.corpus, b, out=self.xp)
             else:
                 e.pack_x(self.corpus, b, out=self.xp)
             mark(2)
-            if self.path == "fast32":
+            if self.path == "fast16":
+                planes = self.S.view(self.torch.int16)[:e.planar_elems(b) + 64]
+                e.crp_keys16(self.corpus, b, self.xp, self.koffs[i], out=planes)
+            elif self.path == "fast32":
                 planes = self.S.view(self.torch.int32)[:e.planar_elems(b)]
                 e.crp_planar32(self.corpus, b, self.xp, out=planes)
             elif self.path == "fast":
@@ -225,7 +238,9 @@ class Runner(object):
             else:
                 e.crp(self.corpus, b, self.xp, sqrt_out=False, out=self.S)
             mark(3)
-            if self.path == "fast32":
+            if self.path == "fast16":
+                e.mask_bits_keys16(planes, self.bands[i], self.koffs[i], self.xp, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
+            elif self.path == "fast32":
                 e.mask_bits_planar32(planes, self.bands[i], self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
             elif self.path == "fast":
                 e.mask_bits_planar(planes, self.corpus, b, self.kappa, True, out=self.bits, work=self.work)
@@ -653,9 +668,14 @@ def main():
         key = None
         if args.path == "staged":
             kname, kms, kwork = "csm_kernel<double,12> (CRPUtils.py:67)", stage_ms["csm"], runner.csm_bytes
+        elif args.path == "fast16":
+            kname = ("crp_rows32_kernel<12,1> (CRPUtils.py:67 + :24 fused, f32 MFMA, 16-bit keys out: 2 B / cell; float32 recompute of "
+                     "the cells in reach of the error band in the selection kernels, exact f64 refinement in select_fix_side16_kernel)")
+            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_rows32_kernel<12, 1>"
         elif args.path == "fast32":
-            kname = ("crp_strip32_kernel<12> (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
-                     "refinement in select_fix_side_kernel)")
+            form = "rows32_kernel<12,0>" if os.environ.get("ACOSS_STRIP32_FORM", "r")[0] != "c" else "strip32_kernel<12>"
+            kname = ("crp_%s (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
+                     "refinement in select_fix_side_kernel)" % form)
             kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip32_kernel<12, 0>"
         elif args.path == "fast":
             kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
@@ -666,7 +686,8 @@ def main():
         achieved, peak, unit, bound = kwork / (kms * 1e-3) / 1e9, HBM_PEAK_GBS, "GB/s", "hbm"
         if key:
             traffic, traffic_src = pmc_traffic(args.path, key, P, args.frames)
-    dtype = {"fast32": "f32 filter + f64 exact refinement (results identical to f64)",
+    dtype = {"fast16": "f32 filter (16-bit keys) + f64 exact refinement (results identical to f64)",
+             "fast32": "f32 filter + f64 exact refinement (results identical to f64)",
              "fused": "f32 filter + f64 exact refinement (results identical to f64)"}.get(args.path, "f64")
     out = {
         "metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)",
@@ -687,7 +708,7 @@ def main():
         "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
     }
     extras = rank == 0 and world == 1 and not args.no_extras
-    if extras and args.path in ("fast", "fast32", "fast_f64", "fused"):
+    if extras and args.path in ("fast16", "fast", "fast32", "fast_f64", "fused"):
         # get_csm as an API (the kernel the north star names) on the same batch, outside the timed
         # region, reported beside the path's own dominant kernel: the plain VALU kernel and the
         # persistent matrix-core strip kernel (bit-identical outputs)
@@ -709,17 +730,26 @@ def main():
         out["hbm_write_ceiling"] = {"kernel": "torch fill_ of the CSM buffer, %d bytes (plain streaming stores)" % fb,
                                     "achieved": round(fb / fms / 1e6, 1), "unit": "GB/s", "avg_launch_ms": round(fms, 4)}
         del C, xp
-        if args.path == "fast32":
+        if args.path in ("fast16", "fast32"):
             # the two selection kernels that read the key matrix back (CRPUtils.py:169-219), on the timed placement: the
             # non-mutual call runs rows + refinement + combine, the mutual one adds the column kernel
-            planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
-            engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
-            t_rows = time_kernel(lambda: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, False, out=runner.bits, work=runner.work), torch)
-            t_both = time_kernel(lambda: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, True, out=runner.bits, work=runner.work), torch)
-            kb = 4.0 * float(np.sum((b.descs["nx"].astype(np.float64) - m + 1) * (b.descs["ny"].astype(np.float64) - m + 1)))
+            cellb = 2.0 if args.path == "fast16" else 4.0
+            if args.path == "fast16":
+                planes = runner.S.view(torch.int16)[:engine.planar_elems(b) + 64]
+                engine.crp_keys16(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), runner.koffs[-1], out=planes)
+                sel = lambda mutual: engine.mask_bits_keys16(planes, runner.bands[-1], runner.koffs[-1], runner.xp, corpus, b, kappa, mutual,
+                                                             out=runner.bits, work=runner.work)
+                names = "select_rows_k16_kernel (+ select_fix_side16 + combine_bits: the non-mutual call) / select_cols_k16_kernel"
+            else:
+                planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
+                engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
+                sel = lambda mutual: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, mutual, out=runner.bits, work=runner.work)
+                names = "select_rows_planar_kernel (+ select_fix_side + combine_bits: the non-mutual call) / select_cols_planar_kernel"
+            t_rows = time_kernel(lambda: sel(False), torch)
+            t_both = time_kernel(lambda: sel(True), torch)
+            kb = cellb * float(np.sum((b.descs["nx"].astype(np.float64) - m + 1) * (b.descs["ny"].astype(np.float64) - m + 1)))
             out["roofline_selection"] = {
-                "kernels": "select_rows_planar_kernel (+ select_fix_side + combine_bits: the non-mutual call) / select_cols_planar_kernel "
-                           "(mutual call minus non-mutual call); each reads the key matrix once, 4 B / cell",
+                "kernels": names + " (mutual call minus non-mutual call); each reads the key matrix once, %d B / cell" % int(cellb),
                 "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_launch": kb,
                 "rows_call_ms": round(t_rows, 4), "rows_achieved": round(kb / t_rows / 1e6, 1), "rows_frac": round(kb / t_rows / 1e6 / HBM_PEAK_GBS, 4),
                 "cols_ms": round(t_both - t_rows, 4), "cols_achieved": round(kb / (t_both - t_rows) / 1e6, 1),
@@ -777,7 +807,7 @@ def main():
         del runner, events
         engine.release_scratch()
         # the same steps through the other compositions of the chain: scores must equal the headline's on every pair
-        for key, other in (("f64_path", "fast"), ("fused", "fused")):
+        for key, other in (("keys32_path", "fast32"), ("f64_path", "fast"), ("fused", "fused")):
             if other == args.path or pitch != 32:
                 continue
             try:

@@ -275,6 +275,23 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
                                    int d, const acoss_pair_desc *descs, int K, int win,
                                    int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
                                    void *work, size_t work_bytes, void *stream);
+/* The same filter with 16-bit keys (the default of acoss_serra09_scores since round 3; csrc/keys16.h): the float32 windowed
+ * sums of acoss_crp_planar32_batch leave the chip as ONE uint16 per cell,
+ *     key16 = min((float32 bits -saturating koff[pair]) >> 10, 0xFFFE),      koff[pair] = bit pattern of W_pair 2^-8
+ * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * 16.5 * 2^-24) of `band`):
+ * 13 mantissa bits over the eight octaves below W_pair, same element indexing as the uint32 matrix (element = 2 bytes).
+ * acoss_mask_bits_keys16_batch selects on those keys; where the winner's error band can reach another key it recomputes
+ * the float32 values of the few cells involved from xp / f32 / n32 (the operands acoss_crp_keys16_batch was given, same
+ * descriptors) with the strip kernel's arithmetic, and what float32 cannot decide is finished exactly in float64 from
+ * feats / norms as in acoss_mask_bits_planar32_batch.  Masks identical to acoss_mask_bits_batch on the float64 sums.
+ * CRPUtils.py:67-84 + :24-45 + :169-219; d in {12, 13}, win == 9, matrices up to 1024 x 1024; work / bits sizes as for
+ * acoss_mask_bits_batch. */
+int acoss_crp_keys16_batch(const float *xp, const float *feats, const float *norms, int d, const acoss_pair_desc *descs,
+                           int K, int win, int max_nx, int max_ny, const uint32_t *koff, uint16_t *out, void *stream);
+int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                 const float *f32, const float *n32, const double *feats, const double *norms, int d,
+                                 const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
+                                 int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);
 /* The product path: get_csm + sliding_csm + csm_to_binary_mutual (CRPUtils.py:67-84, :24-45, :201-219) without any
  * matrix in HBM.  One kernel forms a 24-row band of a pair's windowed sums in float32 on the matrix cores, keeps the
  * band's keys in registers, selects each row's k-th smallest and writes only the row's bit plane; run on (x, y) it
