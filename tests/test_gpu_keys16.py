@@ -1,0 +1,190 @@
+"""The float32 filter with 16-bit keys (csrc/keys16.h, csrc/keys16_kernels.hip, the row-band strip kernel's OUT = 1 form):
+the key plane against its definition, and the masks against the float64 path's bit for bit -- golden 1000-frame pairs,
+ragged pairs with every pitch alignment, kappa conventions, crafted exact ties and 1e-11 perturbations (everything in
+reach of the error band: float64 refinement), a worthless approximation (whole rows in reach: the general refinement),
+13-dimensional features without OTI, thresholds outside the key range (clamped keys: handed over), a side buffer too
+small for the batch (the strided refinement kernels), corpora scaled by 1e+-25."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from acoss_amd import engine
+    engine.require_gpu()
+    return engine
+
+
+def _cells(d):
+    M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
+    return M, N, (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+
+
+def _chain(eng, corpus, batch):
+    xp32 = eng.pack_x32(corpus, batch)
+    koff = eng.keys16_koff(corpus, batch)
+    band = eng.planar32_band(corpus, batch)
+    return xp32, koff, band, eng.crp_keys16(corpus, batch, xp32, koff)
+
+
+def _tie_corpus():
+    """Periodic songs (every row holds a handful of distinct values, each many times: exact ties) and copies of them with
+    1e-11 perturbations (values the float32 filter cannot tell apart)."""
+    rng = np.random.default_rng(5)
+    pat7, pat5 = rng.random((7, 12)) + 0.1, rng.random((5, 12)) + 0.1
+    A = np.tile(pat7, (30, 1))[:200]
+    Bs = np.tile(pat5, (31, 1))[:151]
+    C = A + 1e-11 * rng.random(A.shape)
+    Dn = Bs + 1e-11 * rng.random(Bs.shape)
+    feats = np.concatenate([A, Bs, C, Dn])
+    off = np.cumsum([0, len(A), len(Bs), len(C), len(Dn)]).astype(np.int64)
+    gc = np.stack([x.sum(0) / x.sum(0).max() for x in (A, Bs, C, Dn)])
+    return feats, off, gc, np.array([(i, j) for i in range(4) for j in range(4)], dtype=np.int32)
+
+
+def test_key_plane_is_the_quantised_float32_matrix(eng, golden):
+    """key16 = min((float32 bits -sat koff) >> 10, 0xFFFE) of exactly the values crp_planar32 writes (same arithmetic in
+    the row-band and the column-strip kernel), for every pitch alignment; koff is the pattern of 2 W 2^-8."""
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"]),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32))]
+    for (feats, off, gc, pairs), align in [(c, a) for c in cases for a in (32, 2, 1)]:
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+        eng.oti(corpus, batch)
+        xp32, koff, band, k16 = _chain(eng, corpus, batch)
+        k32 = eng.crp_planar32(corpus, batch, xp32).cpu().numpy().view(np.uint32).astype(np.int64) & 0x7fffffff
+        k16 = k16.cpu().numpy().view(np.uint16).astype(np.int64)
+        ko = koff.cpu().numpy().view(np.uint32).astype(np.int64)
+        w = corpus.song_wmax(9)
+        for p in range(batch.K):
+            M, N, idx = _cells(batch.descs[p])
+            want = np.minimum(np.maximum(k32[idx] - ko[p], 0) >> 10, 0xFFFE)
+            assert np.array_equal(k16[idx], want), (align, p)
+            W2 = 2.0 * (w[batch.descs["song_x"][p]] + w[batch.descs["song_y"][p]])
+            top = np.array([ko[p] + (8 << 23)], dtype=np.uint32).view(np.float32)[0]
+            assert W2 <= top <= W2 * (1 + 2.0 ** -22)
+
+
+def test_masks_equal_the_float64_masks(eng, golden):
+    import torch
+    from acoss_amd import synth
+    g = golden("pairs_1000")
+    lens = iter([9, 40, 65, 129, 300, 1032])
+    small = synth.make_corpus(3, 2, seed=83, lengths=lambda r: next(lens))
+    tf, to, tg, tp = _tie_corpus()
+    cases = [(g["feats"], g["frame_off"], g["gchroma"], g["pairs"], (0.095, 0.5, 3, 0)),
+             (small.feats, small.frame_off, small.gchroma, np.array([(i, j) for i in range(6) for j in range(6)], dtype=np.int32), (0.095, 0.5, 3, 0)),
+             (tf, to, tg, tp, (0.095,))]
+    for ci, (feats, off, gc, pairs, kappas) in enumerate(cases):
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        for align in (32, 2, 1):
+            batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=align)
+            eng.oti(corpus, batch)
+            T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+            xp32, koff, band, k16 = _chain(eng, corpus, batch)
+            for mutual in (True, False):
+                for kappa in kappas:
+                    want, _ = eng.mask_bits(T, batch, kappa, mutual=mutual)
+                    got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, kappa, mutual=mutual)
+                    if not torch.equal(got, want):
+                        for p in range(batch.K):
+                            assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (ci, align, mutual, kappa, p)
+
+
+def test_useless_approximation_and_signed_13d_features(eng):
+    """Features with a large per-bin offset (norms ~1e6, distances ~20): the float32 values are worthless, whole rows lie in
+    reach of the error band (more than 64 cells: hand-over, then the general refinement); and 13-dimensional signed features
+    (the MFCC shape) without OTI."""
+    rng = np.random.default_rng(77)
+    offs = 100.0 * (np.arange(12) + 1.0)
+    lens = [210, 180, 333]
+    feats = np.concatenate([offs[None, :] + rng.standard_normal((n, 12)) for n in lens])
+    off = np.cumsum([0] + lens).astype(np.int64)
+    gc = np.stack([np.abs(rng.standard_normal(12)) for _ in lens])
+    mf = np.concatenate([np.cumsum(rng.standard_normal((n, 13)), axis=0) * 3.0 for n in lens])
+    pairs = np.array([(0, 1), (1, 2), (2, 0), (1, 1)], dtype=np.int32)
+    for F, do_oti in ((feats, True), (mf, False)):
+        corpus = eng.DeviceCorpus(F, off, gchroma=gc)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+        if do_oti:
+            eng.oti(corpus, batch)
+        T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+        xp32, koff, band, k16 = _chain(eng, corpus, batch)
+        for mutual in (True, False):
+            want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+            got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, mutual=mutual)
+            for p in range(batch.K):
+                assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (do_oti, mutual, p)
+
+
+def test_thresholds_outside_the_key_range(eng, orc):
+    """A song with long near-silent passages next to loud ones: the windowed sums of whole rows lie more than eight octaves
+    below 2 W (their keys clamp to 0, so does the threshold: handed over and refined exactly), others clamp at the top.
+    Masks equal the float64 path's, scores the oracle's."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(12)
+    ch = synth.make_corpus(2, 2, seed=12, lengths=lambda r: 260)
+    feats = ch.feats.copy()
+    off = ch.frame_off
+    # songs 0 and 2: frames 60..200 almost identical to each other and tiny in spread (quiet passage), the rest as generated
+    for s_ in (0, 2):
+        a = int(off[s_])
+        feats[a + 60:a + 200] = 0.3 + 1e-4 * rng.random((140, 12))
+    gc = np.stack([feats[off[i]:off[i + 1]].sum(0) / feats[off[i]:off[i + 1]].sum(0).max() for i in range(4)])
+    corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+    pairs = np.array([(0, 2), (2, 0), (0, 1), (1, 2), (0, 0), (3, 1)], dtype=np.int32)
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    xp32, koff, band, k16 = _chain(eng, corpus, batch)
+    kh = k16.cpu().numpy().view(np.uint16)
+    M, N, idx = _cells(batch.descs[0])
+    assert (np.sort(kh[idx], axis=1)[:, int(round(0.095 * N)) - 1] == 0).sum() > 50       # thresholds that left the range
+    for mutual in (True, False):
+        want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+        got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, mutual=mutual)
+        for p in range(batch.K):
+            assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (mutual, p)
+    res = eng.serra09_scores(corpus, pairs)
+    for t, (i, j) in enumerate(pairs):
+        q, d = orc.serra09_pair(feats[off[i]:off[i + 1]], gc[i], feats[off[j]:off[j + 1]], gc[j])
+        assert res["qmax"][t] == q and res["dmax"][t] == d, t
+
+
+def test_side_buffer_overflow_goes_the_strided_way(eng):
+    """More undecided rows than the side buffer holds (the tie corpus repeated: every row and column is undecided, the buffer
+    takes 2 % of them): the rest is finished by the strided refinement kernels from the key plane itself."""
+    import torch
+    tf, to, tg, tp = _tie_corpus()
+    corpus = eng.DeviceCorpus(tf, to, gchroma=tg)
+    pairs = np.tile(np.array([(0, 2), (2, 0), (1, 3), (0, 0), (2, 2), (3, 1)], dtype=np.int32), (40, 1))      # 240 pairs, ~80 000 rows + columns
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    xp32, koff, band, k16 = _chain(eng, corpus, batch)
+    want, _ = eng.mask_bits(T, batch, 0.095, mutual=True)
+    got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, mutual=True)
+    assert torch.equal(got, want)
+
+
+def test_scale_free(eng, orc):
+    """Corpora of very large and very small magnitude through the product chain (16-bit keys are its default)."""
+    from acoss_amd import synth
+    lens = iter([300, 220, 410])
+    ch = synth.make_corpus(3, 1, seed=19, lengths=lambda r: next(lens))
+    pairs = np.array([(0, 1), (1, 2), (2, 0)], dtype=np.int32)
+    assert eng.keys16_default()
+    for mag in (1e25, 1e-25):
+        feats = ch.feats * mag
+        corpus = eng.DeviceCorpus(feats, ch.frame_off, gchroma=ch.gchroma)
+        got = eng.serra09_scores(corpus, pairs, approx32=True)
+        for t, (i, j) in enumerate(pairs):
+            q, d = orc.serra09_pair(feats[ch.frame_off[i]:ch.frame_off[i + 1]], ch.gchroma[i],
+                                    feats[ch.frame_off[j]:ch.frame_off[j + 1]], ch.gchroma[j])
+            assert got["qmax"][t] == q and got["dmax"][t] == d, (mag, t)
