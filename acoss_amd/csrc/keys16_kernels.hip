@@ -348,6 +348,7 @@ extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float 
     else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
     int rc = launch_check("select_rows_k16_kernel");
     if (rc) return rc;
+    if (mutual == 2) return ACOSS_OK;           // measurement: the row selection kernel alone (bench.py's roofline_selection)
     if (mutual) {
         if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
         else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);

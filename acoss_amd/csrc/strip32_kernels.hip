@@ -296,8 +296,9 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     const int cr0 = ce0 / R32_CARRY, cc0 = ce0 - cr0 * R32_CARRY, cr1 = ce1 / R32_CARRY, cc1 = ce1 - cr1 * R32_CARRY;
     const bool carrier = tid < R32_CR * R32_CARRY / 2;
     float pa[R32_RPW], pb[R32_RPW];          // the previous chunk's sums of this lane, per row
+    uint32_t ppk[R32_RPW];                   // (OUT == 1) ... as packed 16-bit keys: the lane's left column in the low half
 #pragma unroll
-    for (int q = 0; q < R32_RPW; q++) pa[q] = pb[q] = 0.0f;
+    for (int q = 0; q < R32_RPW; q++) { pa[q] = pb[q] = 0.0f; ppk[q] = 0u; }
 
     // block [128 (t-1), 128 t) of row q: previous chunk's lanes [sh, 64) then the current chunk's lanes [0, sh).
     // FAST (block-uniform): whole band inside the matrix, even layout, block inside the row: one unconditional 8-byte store.
@@ -334,6 +335,36 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
             const int col = (t - 1) * R32_CW + 2 * lane;
             if (col < N) __builtin_amdgcn_raw_buffer_store_b32(r0, orsrc, 8 * lane, soff, S32_STORE_POLICY);
             if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(r1, orsrc, 8 * lane + 4, soff, S32_STORE_POLICY);
+        }
+    };
+    // the same for the 16-bit plane: keys are formed BEFORE the rows are brought into place, two per register, so an even
+    // shift moves both with one select and one ds_bpermute, an odd one takes the two halves from neighbouring source lanes
+    auto key16 = [&](const float v) { return min(__builtin_elementwise_sub_sat(__float_as_uint(v) & 0x7fffffffu, koff) >> 10, 0xFFFEu); };
+    auto emit16 = [&](const int t, const int q, const uint32_t cpk, auto fast_tag, auto bw_tag) {
+        constexpr bool FAST = decltype(fast_tag)::value;
+        constexpr int BW = decltype(bw_tag)::value;
+        constexpr int dummy = 0;
+        (void)dummy;
+        const int sigma = R32_CARRY - BW - q;
+        const int sh0 = sigma >> 1, sh1 = (sigma + 1) >> 1;
+        uint32_t r;
+        if ((sigma & 1) == 0) {
+            const uint32_t x = lane < sh0 ? cpk : ppk[q];
+            r = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh0) & 63) << 2, (int)x);
+        } else {
+            const uint32_t x0 = lane < sh0 ? cpk : ppk[q], x1 = lane < sh1 ? cpk : ppk[q];
+            const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh0) & 63) << 2, (int)x0);      // its high half opens the pair
+            const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + sh1) & 63) << 2, (int)x1);      // its low half closes it
+            r = __builtin_amdgcn_alignbit(b1, b0, 16);
+        }
+        const int gi = R0 + wave * R32_RPW + q;
+        const int soff = 2 * (gi * ds.crp_pitch + (t - 1) * R32_CW);
+        if (FAST) {
+            __builtin_amdgcn_raw_buffer_store_b32(r, orsrc, 4 * lane, soff, S32_STORE_POLICY);
+        } else if (gi < M) {
+            const int col = (t - 1) * R32_CW + 2 * lane;
+            if (col < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(r & 0xFFFFu), orsrc, 4 * lane, soff, S32_STORE_POLICY);
+            if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(r >> 16), orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
         }
     };
     const bool fast_band = even_layout && (R0 + R32_BR <= M);      // block-uniform
@@ -382,9 +413,15 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
             v2f32 s = v[q];
 #pragma unroll
             for (int k = 1; k < S32_WIN; k++) s += v[q + k];
-            if (t > 0) emit(t, q, s.x, s.y, fast_tag, bw_tag);
-            pa[q] = s.x;
-            pb[q] = s.y;
+            if constexpr (OUT == 1) {
+                const uint32_t cpk = key16(s.x) | (key16(s.y) << 16);
+                if (t > 0) emit16(t, q, cpk, fast_tag, bw_tag);
+                ppk[q] = cpk;
+            } else {
+                if (t > 0) emit(t, q, s.x, s.y, fast_tag, bw_tag);
+                pa[q] = s.x;
+                pb[q] = s.y;
+            }
         }
         lds_barrier();
         if (carrier) {
@@ -402,13 +439,19 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         for (; t <= t_fast; t++) chunk(t, std::true_type{}, std::integral_constant<int, 1>{});
         for (; t < n_chunks; t++) chunk(t, std::false_type{}, std::integral_constant<int, 1>{});
 #pragma unroll
-        for (int q = 0; q < R32_RPW; q++) emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 1>{});
+        for (int q = 0; q < R32_RPW; q++) {
+            if constexpr (OUT == 1) emit16(n_chunks, q, 0u, std::false_type{}, std::integral_constant<int, 1>{});
+            else emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 1>{});
+        }
     } else {
         int t = 0;
         for (; t <= t_fast; t++) chunk(t, std::true_type{}, std::integral_constant<int, 0>{});
         for (; t < n_chunks; t++) chunk(t, std::false_type{}, std::integral_constant<int, 0>{});
 #pragma unroll
-        for (int q = 0; q < R32_RPW; q++) emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 0>{});
+        for (int q = 0; q < R32_RPW; q++) {
+            if constexpr (OUT == 1) emit16(n_chunks, q, 0u, std::false_type{}, std::integral_constant<int, 0>{});
+            else emit(n_chunks, q, 0.0f, 0.0f, std::false_type{}, std::integral_constant<int, 0>{});
+        }
     }
 }
 

@@ -372,8 +372,8 @@ def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True
         work = torch.empty(need, dtype=torch.uint8, device=keys16.device)
     check(lib.acoss_mask_bits_keys16_batch(_ptr(keys16), _ptr(band), _ptr(koff), _ptr(xp32), _ptr(f32), _ptr(n32), _ptr(corpus.feats),
                                            _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
-                                           batch.max_ny, float(kappa), int(bool(mutual)), _ptr(out), _ptr(work), work.numel(),
-                                           _stream()), "mask_bits_keys16_batch")
+                                           batch.max_ny, float(kappa), 2 if mutual == "rows_kernel_only" else int(bool(mutual)), _ptr(out), _ptr(work),
+                                           work.numel(), _stream()), "mask_bits_keys16_batch")
     return out, work
 
 
@@ -642,7 +642,7 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     """The scorer's device scratch (grow-only, shared by successive calls).  The kernels that write and read the big
     intermediate run 5-10 % faster or slower depending on WHICH allocation it lives in (a property of
     the allocation's physical backing, stable for its lifetime), so a new buffer of more than 4 GiB is chosen among
-    ACOSS_SCRATCH_TRIALS (default 4, as memory allows) candidates by timing one batch of the call at hand in each;
+    ACOSS_SCRATCH_TRIALS (default 2, as memory allows) candidates by timing one batch of the call at hand in each;
     ACOSS_SCRATCH_ARENA_GB=<n> scans the windows of one n-GB arena instead."""
     key = ("scorer", str(device), torch.uint8)
     buf = _SCRATCH.get(key)
@@ -652,7 +652,7 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     buf = None
     torch.cuda.empty_cache()
     size = int(need * 1.05) + 16
-    trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "4")))
+    trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "2")))
     free_b = torch.cuda.mem_get_info(device)[0]
     trials = max(1, min(trials, int(0.6 * free_b // max(size, 1))))
     arena_gb = float(os.environ.get("ACOSS_SCRATCH_ARENA_GB", "0"))

@@ -80,7 +80,7 @@ class Runner(object):
     sliding -> binarise -> qmax, one kernel per reference function.  All buffers are preallocated and every launch goes to
     torch's current stream; HIP events between the stages give per-stage times of the timed steps."""
 
-    def __init__(self, corpus, batches, m, kappa, path):
+    def __init__(self, corpus, batches, m, kappa, path, arena_gb=None):
         import torch
         from acoss_amd import engine
         self.engine, self.torch, self.path = engine, torch, path
@@ -126,19 +126,22 @@ class Runner(object):
             self.koffs = [engine.keys16_koff(corpus, b) for b in batches]
         if path == "fused":
             self.bands = [engine.planar32_band(corpus, b, fused=True) for b in batches]
-        # The times of the kernels that write and read the big intermediate depend on which allocation it lives in (DESIGN.md
-        # section 4a: the strip kernel 3.65-3.93 ms, the row selection 2.90-3.37 ms for eight 16 GB buffers in one process,
-        # moving against each other; any offset inside a buffer gives the same times).  Try a few placements once, before
-        # anything is timed, and keep the one with the shortest strip + selection time.
+        # Placement: the kernels that write and read the key matrix run up to 10 % faster or slower depending on which physical
+        # memory it lives in.  Round 3 closed the question with one experiment (tools/vmm_probe.py,
+        # profiles/r03_vmm_placement_probe.txt): no allocation path (hipMalloc, torch's allocator, hipMemCreate in one chunk or
+        # in 1 GB / 2 MB chunks; the recommended granularity is 4 KB) yields the fast class deterministically, so the scan
+        # of arena windows is OFF by default -- the headline is what a plain allocation gives -- and ACOSS_BENCH_ARENA_GB=<n>
+        # turns it on (the `placement_scanned` block of the JSON line reports it beside the headline).
         self.placement_ms = None
-        if self.planar and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
+        if arena_gb is None:
+            arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "0"))
+        if self.planar and arena_gb > 0 and not os.environ.get("ACOSS_BENCH_NO_PLACEMENT"):
             b0 = batches[0]
             engine.oti(corpus, b0)
             # candidates: windows of ONE large arena, 4 GiB apart (regions of an arena differ as much as separate allocations
             # do, tools/placement_probe4.py, and a scan costs no further allocations), the buffer allocated above among them
             win_bytes = self.S.numel() * 8
             free_b = torch.cuda.mem_get_info(dev)[0]
-            arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "160"))
             arena_bytes = int(min(arena_gb * (1 << 30), 0.6 * free_b))
             cands, where = [self.S], ["own"]
             self.arena = _ARENA.get(str(dev))             # one arena per process and device, shared by the side blocks' runners
@@ -320,6 +323,47 @@ def pmc_traffic(path, kernel_key, P, frames):
             return (round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9),
                     "profiles/%s (rocprofv3 --pmc WRITE_SIZE / FETCH_SIZE passes on this workload)" % name)
     return None, None
+
+
+def attach_profile_averages(out, P, args):
+    """Beside every live roofline block the average duration of the same kernel in the committed rocprofv3 --kernel-trace
+    --stats summary (profiles/r03_kernel_stats.csv, collected by tools/collect_profiles.sh with this file's own command) and
+    the fraction that follows from it -- only when the profile was taken on this workload (pairs per step, frames, path)."""
+    import csv
+    meta_f = os.path.join(ROOT, "profiles", "r03_profile_meta.json")
+    stats_f = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
+    if not (os.path.exists(meta_f) and os.path.exists(stats_f)):
+        return
+    with open(meta_f) as fh:
+        meta = json.load(fh)
+    if meta.get("pairs_per_step") != P or meta.get("frames") != args.frames or meta.get("path") != args.path or meta.get("songs") != args.songs:
+        return
+    avg = {}
+    with open(stats_f) as fh:
+        for row in csv.DictReader(fh):
+            avg[row["Name"]] = float(row["AverageNs"]) * 1e-6
+
+    def find(prefix):
+        for name, ms in avg.items():
+            if prefix in name:
+                return ms
+        return None
+    blocks = [out.get("roofline")]
+    if "roofline_selection" in out:
+        blocks += [out["roofline_selection"].get("rows"), out["roofline_selection"].get("cols")]
+    for blk in blocks:
+        if not blk:
+            continue
+        key = blk["kernel"].split(" ")[0]
+        key = {"crp_rows32_kernel<12,1>": "crp_rows32_kernel<12, 1>", "crp_rows32_kernel<12,0>": "crp_rows32_kernel<12, 0>",
+               "crp_strip32_kernel<12>": "crp_strip32_kernel<12, 0>"}.get(key, key)
+        ms = find(key)
+        if ms is None:
+            continue
+        work = blk.get("bytes_per_launch") or blk.get("flops_per_launch")
+        blk["profiles_avg_launch_ms"] = round(ms, 4)
+        blk["profiles_frac"] = round(work / ms / 1e6 / blk["peak"], 4) if blk["unit"] == "GB/s" else None
+        blk["profiles_source"] = "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `%s`)" % meta.get("command", "bench.py")
 
 
 def extras_config3(engine, synth, oracle, threads, torch):
@@ -731,29 +775,37 @@ def main():
                                     "achieved": round(fb / fms / 1e6, 1), "unit": "GB/s", "avg_launch_ms": round(fms, 4)}
         del C, xp
         if args.path in ("fast16", "fast32"):
-            # the two selection kernels that read the key matrix back (CRPUtils.py:169-219), on the timed placement: the
-            # non-mutual call runs rows + refinement + combine, the mutual one adds the column kernel
+            # the two selection kernels that read the key matrix back (CRPUtils.py:169-219), on the timed buffers, each timed
+            # live with HIP events: rows = the row kernel alone (fast16; for fast32 the non-mutual call, which also holds the
+            # refinement and the combine kernel), cols = mutual call minus non-mutual call
             cellb = 2.0 if args.path == "fast16" else 4.0
             if args.path == "fast16":
                 planes = runner.S.view(torch.int16)[:engine.planar_elems(b) + 64]
                 engine.crp_keys16(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), runner.koffs[-1], out=planes)
                 sel = lambda mutual: engine.mask_bits_keys16(planes, runner.bands[-1], runner.koffs[-1], runner.xp, corpus, b, kappa, mutual,
                                                              out=runner.bits, work=runner.work)
-                names = "select_rows_k16_kernel (+ select_fix_side16 + combine_bits: the non-mutual call) / select_cols_k16_kernel"
+                t_rowk = time_kernel(lambda: sel("rows_kernel_only"), torch)
+                rname, cname = "select_rows_k16_kernel<12>", "select_cols_k16_kernel<12>"
             else:
                 planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
                 engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
                 sel = lambda mutual: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, mutual, out=runner.bits, work=runner.work)
-                names = "select_rows_planar_kernel (+ select_fix_side + combine_bits: the non-mutual call) / select_cols_planar_kernel"
+                t_rowk = None
+                rname, cname = "select_rows_planar_kernel<0, 16>", "select_cols_planar_kernel<0>"
             t_rows = time_kernel(lambda: sel(False), torch)
             t_both = time_kernel(lambda: sel(True), torch)
             kb = cellb * float(np.sum((b.descs["nx"].astype(np.float64) - m + 1) * (b.descs["ny"].astype(np.float64) - m + 1)))
+
+            def blk(kernel, ms, note):
+                return {"kernel": kernel, "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_launch": kb, "avg_launch_ms": round(ms, 4),
+                        "achieved": round(kb / ms / 1e6, 1), "frac": round(kb / ms / 1e6 / HBM_PEAK_GBS, 4), "measured": note}
             out["roofline_selection"] = {
-                "kernels": names + " (mutual call minus non-mutual call); each reads the key matrix once, %d B / cell" % int(cellb),
-                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "bytes_per_launch": kb,
-                "rows_call_ms": round(t_rows, 4), "rows_achieved": round(kb / t_rows / 1e6, 1), "rows_frac": round(kb / t_rows / 1e6 / HBM_PEAK_GBS, 4),
-                "cols_ms": round(t_both - t_rows, 4), "cols_achieved": round(kb / (t_both - t_rows) / 1e6, 1),
-                "cols_frac": round(kb / (t_both - t_rows) / 1e6 / HBM_PEAK_GBS, 4)}
+                "rows": blk(rname, t_rowk if t_rowk is not None else t_rows,
+                            "HIP events around the kernel alone" if t_rowk is not None else "HIP events around the non-mutual call (rows + refinement + combine)"),
+                "cols": blk(cname, t_both - t_rows, "HIP events: mutual call minus non-mutual call"),
+                "rows_call_ms": round(t_rows, 4), "both_call_ms": round(t_both, 4),
+                "note": "each kernel reads the key matrix once, %d B / cell; both are bound by instruction issue and, for the columns, the "
+                        "LDS staging round trip rather than by HBM (DESIGN.md section 4b)" % int(cellb)}
     threads = max(1, min(os.cpu_count() or 1, 16))
     if rank == 0 and not args.no_cpu_baseline:
         # (N > 1: rank 0 computes it after the timed region, the other ranks are done)
@@ -804,8 +856,25 @@ def main():
     if extras:
         from oracle import oracle
         last = scores[args.warmup:].clone()
+        runner_had_no_scan = runner.placement_ms is None
         del runner, events
         engine.release_scratch()
+        # the headline's path once more with the key matrix placed by a scan of arena windows (what round 2's headline did)
+        if runner_had_no_scan and args.path in ("fast16", "fast32", "fast"):
+            try:
+                rs = Runner(corpus, batches, m, kappa, args.path, arena_gb=float(os.environ.get("ACOSS_BENCH_SCAN_GB", "160")))
+                el_s, s_s, st_s = timed_steps(rs, n_steps, args.warmup, P, dev, torch)
+                out["placement_scanned"] = {"value": round(args.steps * P / el_s, 1), "unit": "pair-scores/s", "ms_per_step": round(1e3 * el_s / args.steps, 3),
+                                            "stage_ms": st_s, "scan": rs.placement_ms,
+                                            "scores_identical_to_headline": bool(torch.equal(s_s[args.warmup:], last)),
+                                            "note": "the headline uses a plain allocation; this block scans 4 GiB-spaced windows of one arena for the "
+                                                    "fastest strip + selection time first (DESIGN.md section 4a: a property of physical memory no "
+                                                    "allocation path controls)"}
+                del rs, s_s
+            except SystemExit:
+                pass
+            _ARENA.clear()
+            engine.release_scratch()
         # the same steps through the other compositions of the chain: scores must equal the headline's on every pair
         for key, other in (("keys32_path", "fast32"), ("f64_path", "fast"), ("fused", "fused")):
             if other == args.path or pitch != 32:
@@ -825,9 +894,11 @@ def main():
                                    "achieved": round(bpl / (st2["crp"] * 1e-3) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(bpl / (st2["crp"] * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "bytes_per_launch": bpl,
                                    "avg_launch_ms": st2["crp"]}
-            else:
+            elif other == "fused":
                 blk["note"] = ("masks from crp_band_kernel (csrc/band_kernels.hip): no matrix in HBM, both orientations recomputed; "
                                "mask_bits holds CSM + window + selection + refinement + combine")
+            else:
+                blk["note"] = "round 2's form of the filter: 32-bit keys (4 B / cell written, 4 + 4 read), row-band strip kernel"
             out[key] = blk
             del r2, s2
             engine.release_scratch()
@@ -860,6 +931,7 @@ def main():
             engine.release_scratch()
             torch.cuda.empty_cache()
     if rank == 0:
+        attach_profile_averages(out, P, args)
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
