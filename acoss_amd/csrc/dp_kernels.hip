@@ -10,6 +10,9 @@
 // The only consumed output in the reference's callers is the maximum cell; D is written only
 // when the caller passes a buffer (parity / drop-in use).
 #include "common.h"
+
+#include <stdlib.h>
+#include <type_traits>
 #include "wave_ops.h"
 #include "thresh_work.h"
 
@@ -527,7 +530,7 @@ template <> struct BitsRow<16> { using type = unsigned short; using ext = unsign
 template <> struct BitsRow<32> { using type = unsigned; using ext = uint64_t; };
 
 template <int KIND, int CPL>
-__global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict__ bits,
+__global__ __launch_bounds__(256, CPL == 16 ? 4 : 2) void dp_bits_kernel(const uint64_t *__restrict__ bits,
                                                       const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                       int max_m, float gamma, int boundary, float4 sw,
                                                       float *__restrict__ scores)
@@ -537,7 +540,9 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
     using ext_t = typename BitsRow<CPL>::ext;
     constexpr int FIRST = (KIND == KIND_DMAX) ? 3 : 2;
     constexpr int R0 = (KIND == KIND_DMAX) ? 1 : 2;
-    constexpr int PF = CPL == 16 ? 16 : 8;
+    // rows per trip of the main loop = rows of mask held ahead in registers: a multiple of 3, so that the three value rows
+    // (i-1, i-2, i-3) return to their registers at the end of a trip and the loop carries no copies
+    constexpr int PF = CPL == 16 ? 12 : 6;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.x * 4 + wave;
     if (p >= K) return;
@@ -550,17 +555,15 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
     }
     const int j0 = lane * CPL;
     const row_t *rowp = reinterpret_cast<const row_t *>(bits + (int64_t)p * max_m * CPL) + lane;
-    unsigned ring[PF];
-#pragma unroll
-    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(R0 + u, M - 1) * 64];
     float d1[CPL], d2[CPL], d3[CPL];
 #pragma unroll
     for (int c = 0; c < CPL; c++) { d1[c] = d2[c] = d3[c] = 0.f; }
     unsigned m1 = 0, m2 = 0;
     float best = 0.0f;
     const bool l0 = lane == 0;
-    auto do_row = [&](const int i, const unsigned m0) {
-        if (i >= FIRST) {
+    // MAIN (compile-time): row i >= FIRST for certain (the main loop): no test
+    auto do_row = [&](const int i, const unsigned m0, auto main_tag) {
+        if (decltype(main_tag)::value || i >= FIRST) {
             const float h1a = lane_shr1(d1[CPL - 1], 0.f), h1b = lane_shr1(d1[CPL - 2], 0.f);
             const float h2a = lane_shr1(d2[CPL - 1], 0.f);
             float h1c = 0.f, h3a = 0.f;
@@ -624,17 +627,23 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
         m2 = m1;
         m1 = m0;
     };
-    for (int ib = R0; ib < M; ib += PF) {
+    // (bits past column N are zero by construction)
+    int i = R0;
+#pragma unroll 1
+    for (; i < min(FIRST, M); i++) do_row(i, (unsigned)rowp[(int64_t)i * 64], std::false_type{});       // rows before the first computed one
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+    for (; i + PF <= M; i += PF) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const int i = ib + u;
-            if (i < M) {
-                const unsigned m0 = ring[u];        // bits past column N are zero by construction
-                if (i + PF < M) ring[u] = rowp[(int64_t)(i + PF) * 64];
-                do_row(i, m0);
-            }
+            const unsigned m0 = ring[u];
+            ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
+            do_row(i + u, m0, std::true_type{});
         }
     }
+#pragma unroll 1
+    for (; i < M; i++) do_row(i, (unsigned)rowp[(int64_t)i * 64], std::true_type{});        // fewer than PF rows left
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) best = fmaxf(best, __shfl_xor(best, off));
     if (lane == 0) scores[p] = best;
@@ -645,14 +654,14 @@ __global__ __launch_bounds__(256) void dp_bits_kernel(const uint64_t *__restrict
 // dependent chains interleave in one instruction stream and the mask is read once.  Same arithmetic per kind as
 // dp_bits_kernel.
 template <int CPL>
-__global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restrict__ bits,
+__global__ __launch_bounds__(256, CPL == 16 ? 2 : 1) void dp_bits_qd_kernel(const uint64_t *__restrict__ bits,
                                                          const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                          int max_m, float gamma, int boundary,
                                                          float *__restrict__ qscores, float *__restrict__ dscores)
 {
     using row_t = typename BitsRow<CPL>::type;
     using ext_t = typename BitsRow<CPL>::ext;
-    constexpr int PF = CPL == 16 ? 16 : 8;
+    constexpr int PF = 6;                       // a multiple of 2 and 3: both recurrences' rows are back in place after a trip
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int p = blockIdx.x * 4 + wave;
     if (p >= K) return;
@@ -666,17 +675,15 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
     }
     const int j0 = lane * CPL;
     const row_t *rowp = reinterpret_cast<const row_t *>(bits + (int64_t)p * max_m * CPL) + lane;
-    unsigned ring[PF];
-#pragma unroll
-    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(1 + u, M - 1) * 64];
     float q1[CPL], q2[CPL], e1[CPL], e2[CPL], e3[CPL];              // qmax rows i-1, i-2; dmax rows i-1, i-2, i-3
 #pragma unroll
     for (int c = 0; c < CPL; c++) { q1[c] = q2[c] = e1[c] = e2[c] = e3[c] = 0.f; }
     unsigned m1 = 0, m2 = 0;
     float qbest = 0.0f, dbest = 0.0f;
     const bool l0 = lane == 0;
-    auto do_row = [&](const int i, const unsigned m0) {
-        if (i >= 2) {       // ---- qmax (rows >= 2)
+    auto do_row = [&](const int i, const unsigned m0, auto main_tag) {
+        constexpr bool MAIN = decltype(main_tag)::value;        // row i >= 3 for certain
+        if (MAIN || i >= 2) {       // ---- qmax (rows >= 2)
             const float h1a = lane_shr1(q1[CPL - 1], 0.f), h1b = lane_shr1(q1[CPL - 2], 0.f);
             const float h2a = lane_shr1(q2[CPL - 1], 0.f);
             float nd[CPL];
@@ -699,7 +706,7 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
             for (int c = 0; c < CPL; c++) { q2[c] = q1[c]; q1[c] = nd[c]; }
         }
         if (do_d) {
-            if (i >= 3) {   // ---- dmax (rows >= 3)
+            if (MAIN || i >= 3) {   // ---- dmax (rows >= 3)
                 const float h1a = lane_shr1(e1[CPL - 1], 0.f), h1b = lane_shr1(e1[CPL - 2], 0.f), h1c = lane_shr1(e1[CPL - 3], 0.f);
                 const float h2a = lane_shr1(e2[CPL - 1], 0.f), h3a = lane_shr1(e3[CPL - 1], 0.f);
                 const unsigned h0 = (unsigned)lane_shr1((int)m0, 0);
@@ -742,17 +749,22 @@ __global__ __launch_bounds__(256) void dp_bits_qd_kernel(const uint64_t *__restr
         m2 = m1;
         m1 = m0;
     };
-    for (int ib = 1; ib < M; ib += PF) {
+    int i = 1;
+#pragma unroll 1
+    for (; i < min(3, M); i++) do_row(i, (unsigned)rowp[(int64_t)i * 64], std::false_type{});
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+    for (; i + PF <= M; i += PF) {
 #pragma unroll
         for (int u = 0; u < PF; u++) {
-            const int i = ib + u;
-            if (i < M) {
-                const unsigned m0 = ring[u];        // bits past column N are zero by construction
-                if (i + PF < M) ring[u] = rowp[(int64_t)(i + PF) * 64];
-                do_row(i, m0);
-            }
+            const unsigned m0 = ring[u];        // bits past column N are zero by construction
+            ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
+            do_row(i + u, m0, std::true_type{});
         }
     }
+#pragma unroll 1
+    for (; i < M; i++) do_row(i, (unsigned)rowp[(int64_t)i * 64], std::true_type{});
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) {
         qbest = fmaxf(qbest, __shfl_xor(qbest, off));
@@ -865,6 +877,15 @@ int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
+    // Round 3: since the single-recurrence kernels lost their per-row branches and register copies (a trip of the main loop is
+    // 12 unconditional rows), qmax and dmax as two launches (0.69 + 1.24 ms per 4096 pairs of 1000-frame songs) beat the
+    // one-sweep kernel (2.02 ms: 230 registers, two waves per SIMD).  ACOSS_DP_ONE_SWEEP=1 keeps the old form.
+    static const bool one_sweep = []() { const char *e = getenv("ACOSS_DP_ONE_SWEEP"); return e && e[0] == '1'; }();
+    if (!one_sweep) {
+        int rc = acoss_align_bits_batch(0, bits, descs, K, win, max_nx, max_ny, 0, params, qmax_scores, stream);
+        if (rc == ACOSS_OK) rc = acoss_align_bits_batch(1, bits, descs, K, win, max_nx, max_ny, boundary, params, dmax_scores, stream);
+        return rc;
+    }
     if (mask_bits_words(max_m, max_n) == 16)
         hipLaunchKernelGGL(dp_bits_qd_kernel<16>, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m,
                            ap.gamma_onset, boundary, qmax_scores, dmax_scores);
