@@ -44,10 +44,13 @@ __device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, i
 }
 
 constexpr int K16_ROWS_PER_WAVE = 16;
+#ifndef K16_ROWS_WPS
+#define K16_ROWS_WPS 8
+#endif
 
 // ---- rows ------------------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, 8) void select_rows_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+__global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                                  int win, double kv, int k_mode, ThreshWork w, int rows_blocks, K16Ctx cx)
 {
     __shared__ __attribute__((aligned(16))) unsigned hist_all[4 * K16_HIST_WORDS];
@@ -77,7 +80,8 @@ __global__ __launch_bounds__(256, 8) void select_rows_k16_kernel(const uint16_t 
         return inside ? reinterpret_cast<const u32x4v *>(base + (int64_t)i * ds.crp_pitch) : reinterpret_cast<const u32x4v *>(k16_pad_block);
     };
     u32x4v na = __builtin_nontemporal_load(row_ptr(r0)), nb = __builtin_nontemporal_load(row_ptr(r0) + 1);
-    uint16_t *out_bits = reinterpret_cast<uint16_t *>(w.row_bits + ((int64_t)p * w.max_m) * 16);
+    // the row's 16 mask bits per lane leave through a raw buffer store: wave-uniform row offset + a constant lane offset
+    const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(w.row_bits + ((int64_t)p * w.max_m) * 16, 0, M * 128, 0x00020000);
     for (int i = r0; i < r1; i++) {
         u16x2 h[8] = {k16_from_u32(na.x), k16_from_u32(na.y), k16_from_u32(na.z), k16_from_u32(na.w),
                       k16_from_u32(nb.x), k16_from_u32(nb.y), k16_from_u32(nb.z), k16_from_u32(nb.w)};
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 8) void select_rows_k16_kernel(const uint16_t 
             }
         }
         if (lane == 0) w.row_cut[(int64_t)p * w.max_m + i] = state == K16_DECIDED ? 0x7fffffff : -3;
-        if (state == K16_DECIDED) out_bits[(int64_t)i * 64 + lane] = (uint16_t)sel;
+        if (state == K16_DECIDED) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sel, brsrc, 2 * lane, i * 128, 0);
     }
 }
 
