@@ -339,7 +339,14 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     };
     // the same for the 16-bit plane: keys are formed BEFORE the rows are brought into place, two per register, so an even
     // shift moves both with one select and one ds_bpermute, an odd one takes the two halves from neighbouring source lanes
-    auto key16 = [&](const float v) { return min(__builtin_elementwise_sub_sat(__float_as_uint(v) & 0x7fffffffu, koff) >> 10, 0xFFFEu); };
+    // (the sums are >= +0 with the sign bit clear: every C is max(., +0), an exact cancellation in the fma rounds to +0.  The
+    // two keys of a lane are clamped to 16 bits by the saturating pack, then to 0xFFFE together)
+    typedef unsigned short u16x2k __attribute__((ext_vector_type(2)));
+    auto keys16 = [&](const float a, const float b) {
+        const u16x2k pk = __builtin_amdgcn_cvt_pk_u16(__builtin_elementwise_sub_sat(__float_as_uint(a), koff) >> 10,
+                                                      __builtin_elementwise_sub_sat(__float_as_uint(b), koff) >> 10);
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk, (u16x2k){(unsigned short)0xFFFEu, (unsigned short)0xFFFEu}));
+    };
     auto emit16 = [&](const int t, const int q, const uint32_t cpk, auto fast_tag, auto bw_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;
         constexpr int BW = decltype(bw_tag)::value;
@@ -414,7 +421,7 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
 #pragma unroll
             for (int k = 1; k < S32_WIN; k++) s += v[q + k];
             if constexpr (OUT == 1) {
-                const uint32_t cpk = key16(s.x) | (key16(s.y) << 16);
+                const uint32_t cpk = keys16(s.x, s.y);
                 if (t > 0) emit16(t, q, cpk, fast_tag, bw_tag);
                 ppk[q] = cpk;
             } else {
