@@ -4,11 +4,14 @@
 // has a neighbour inside the float32 error band are finished in float64.  The selection kernels are bound by the bytes they
 // read and the instructions they spend per key, so the filter's keys shrink to 16 bits:
 //
-//     key16(T~) = min((bits(T~) -sat koff_p) >> 10, 0xFFFE)          bits = the float32 bit pattern (T~ >= +0: monotone)
+//     k' = bits(T~) -sat koff_p                                       bits = the float32 bit pattern (T~ >= +0: monotone)
+//     key16(T~) = min(max(k' >> 11, (k' >> 9) -sat 49152), 0xFFFE)
 //
-// koff_p = the pattern of 2 W_p 2^-8 per pair (W_p = the pair's bound on the window norm sums; no windowed sum exceeds 2 W_p):
-// 13 mantissa bits over the eight octaves below 2 W_p -- thresholds of real rows sit 1.5-3 octaves below 2 W_p.  Values above the range clamp
-// to 0xFFFE, values below it to 0, 0xFFFF pads positions past the end of a row.  The strip kernel (row-band form, OUT = 1)
+// koff_p = the pattern of 2 W_p 2^-7 per pair (W_p = the pair's bound on the window norm sums; no windowed sum exceeds 2 W_p).
+// Two resolutions, one monotone map: the three octaves below 2 W_p -- where the thresholds of real rows sit (1.5 to 2.9 octaves
+// below 2 W_p on every corpus of the benchmarks) -- keep 14 mantissa bits (keys 16384 .. 65534), the four octaves below those
+// 12 bits (keys 0 .. 16383).  Values at the top clamp to 0xFFFE, values below the range to 0, 0xFFFF pads positions past the
+// end of a row.  The strip kernel (row-band form, OUT = 1)
 // writes ONLY this plane: 2 bytes per cell written, 2 read by the row selection, 2 by the column selection (6 bytes per cell
 // and pair instead of 12).
 //
@@ -28,9 +31,10 @@
 
 namespace acoss {
 
-constexpr int K16_S = 10;
+constexpr unsigned K16_FINE = 16384u;                 // first key of the fine region; K16_FINE_BIAS = (4 << 14) - K16_FINE ... 49152
+constexpr unsigned K16_FINE_BIAS = 49152u;
 constexpr unsigned K16_MAX = 0xFFFEu, K16_PAD = 0xFFFFu;
-constexpr int K16_SHIFT0 = 3, K16_SHIFT_MAX = 9;      // histogram bin widths (log2, in keys): the 32-bit selection's window / 2^10
+constexpr int K16_SHIFT0 = 4, K16_SHIFT_MAX = 10;     // histogram bin widths (log2, in keys): the 32-bit selection's window / 2^9
 constexpr int K16_SCRATCH = 256;                      // words of wave-private LDS behind the histogram (slow path): positions,
                                                       // C values, float32 keys, extra mask bits (the last quarter: zero between uses)
 constexpr int K16_HIST_WORDS = HIST256_BINS + 64 + K16_SCRATCH;
@@ -43,7 +47,15 @@ __device__ inline unsigned k16_to_u32(u16x2 v) { return __builtin_bit_cast(unsig
 
 __device__ inline unsigned key16_of_bits(unsigned fbits, unsigned koff)
 {
-    return min(__builtin_elementwise_sub_sat(fbits, koff) >> K16_S, K16_MAX);
+    const unsigned kp = __builtin_elementwise_sub_sat(fbits, koff);
+    return min(max(kp >> 11, __builtin_elementwise_sub_sat(kp >> 9, K16_FINE_BIAS)), K16_MAX);
+}
+
+// the float32 bit patterns a key stands for: [first, first + span)
+__device__ inline void key16_bits_range(unsigned key, unsigned koff, unsigned &first, unsigned &span)
+{
+    if (key >= K16_FINE) { first = koff + ((key + K16_FINE_BIAS) << 9); span = 1u << 9; }
+    else { first = koff + (key << 11); span = 1u << 11; }
 }
 
 // what a lane needs to recompute a cell's float32 windowed sum
@@ -92,18 +104,20 @@ __device__ inline float k16_c_value(const float *__restrict__ xrow0, const float
 }
 
 // [h_lo, h_hi]: the 16-bit keys that can hold a cell within the float32 error band of ANY value whose key is th.
-// Keys of K16_NEAR and above belong to values a >= 2 W 2^-3 (koff is the pattern of 2 W 2^-8 and a key step is 2^-13 octave):
-// there the band, (2 (d + 4.5) W + 19 a) 2^-24 rounded up <= (8 (d + 4.5) + 19) 2^-24 a < 2^-16.7 a for d <= 13, is narrower
-// than the 2^-14 a a key spans at least, so nothing outside [th - 1, th + 1] is in reach: no float arithmetic on the common path.
-constexpr unsigned K16_NEAR = 5u << 13;
+// Keys above K16_FINE belong to values a >= 2 W 2^-3 (koff is the pattern of 2 W 2^-7, the fine region starts four octaves
+// above it) and step by at least 2^-15 a: there the band, (2 (d + 4.5) W + 19 a) 2^-24 rounded up <= (8 (d + 4.5) + 19) 2^-24 a
+// < 2^-16.7 a for d <= 13, is narrower than a key, so nothing outside [th - 1, th + 1] is in reach: no float arithmetic on the
+// common path.
 __device__ inline void k16_reach(unsigned th, unsigned koff, const float *pair_band, unsigned &h_lo, unsigned &h_hi)
 {
-    if (th >= K16_NEAR && th < K16_MAX) {
+    if (th > K16_FINE && th < K16_MAX) {
         h_lo = th - 1u;
         h_hi = min(th + 1u, K16_MAX);
         return;
     }
-    const unsigned b_lo = koff + (th << K16_S), b_hi = b_lo + ((1u << K16_S) - 1u);
+    unsigned b_lo, span;
+    key16_bits_range(th, koff, b_lo, span);
+    const unsigned b_hi = b_lo + span - 1u;
     const float a_lo = __uint_as_float(b_lo), a_hi = __uint_as_float(b_hi);
     const float band = fmaf(pair_band[1], a_hi, pair_band[0]);
     const float l = a_lo - band, h = a_hi + band;

@@ -350,7 +350,7 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
                 float *xp = (float *)(base + v.xp);
                 rc = acoss_pack_x_f32(c->f32, c->n32, c->d, d_descs, B, b.max_nx, xp, st);
                 if (c->keys16) {
-                    // 16-bit keys (csrc/keys16.h): koff = the pattern of the float32 not below 2 W, eight octaves down
+                    // 16-bit keys (csrc/keys16.h): koff = the pattern of the float32 not below 2 W, seven octaves down
                     uint32_t *hk = h_koff + done, *d_koff = (uint32_t *)(base + v.koff);
                     for (int t = 0; t < B; t++) {
                         const double w2 = 2.0 * (w[(size_t)bp[2 * (size_t)t]] + w[(size_t)bp[2 * (size_t)t + 1]]);
@@ -358,7 +358,7 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
                         if ((double)f < w2) f = nextafterf(f, INFINITY);
                         uint32_t fb;
                         memcpy(&fb, &f, 4);
-                        hk[t] = (std::isfinite(f) && f > 7.9e-31f) ? fb - (8u << 23) : 0u;
+                        hk[t] = (std::isfinite(f) && f > 7.9e-31f) ? fb - (7u << 23) : 0u;
                     }
                     ACOSS_HIP(hipMemcpyAsync(d_koff, hk, 4 * (size_t)B, hipMemcpyHostToDevice, st));
                     if (!rc) rc = acoss_crp_keys16_batch(xp, c->f32, c->n32, c->d, d_descs, B, win, b.max_nx, b.max_ny, d_koff, (uint16_t *)(base + v.T), st);

@@ -219,8 +219,8 @@ constexpr int R32_RPW = R32_BR / 8;     // output rows per wave
 #define R32_WPS 6                       // waves per SIMD the register allocation aims at: three blocks per CU (42 KB of LDS each)
 #endif
 
-// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes); 1 = the 16-bit key plane of keys16.h (2 bytes per cell: key16 =
-// min((bits -sat koff[pair]) >> 10, 0xFFFE), `out` is then a uint16 matrix with the same element indexing);
+// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes); 1 = the 16-bit key plane of keys16.h (2 bytes per cell, two
+// resolutions in one monotone map: see there; `out` is then a uint16 matrix with the same element indexing);
 // 2 = no stores (development probe)
 template <int D, int OUT = 0>
 __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *__restrict__ xp, int max_nx,
@@ -320,8 +320,9 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         if (OUT == 2) {
             if (r0 == 0x12345u) __builtin_amdgcn_raw_buffer_store_b32(r1, orsrc, 4 * (lane & 63), 0, 0);
         } else if (OUT == 1) {
-            const uint32_t h0 = min(__builtin_elementwise_sub_sat(r0 & 0x7fffffffu, koff) >> 10, 0xFFFEu);
-            const uint32_t h1 = min(__builtin_elementwise_sub_sat(r1 & 0x7fffffffu, koff) >> 10, 0xFFFEu);
+            const uint32_t k0 = __builtin_elementwise_sub_sat(r0 & 0x7fffffffu, koff), k1 = __builtin_elementwise_sub_sat(r1 & 0x7fffffffu, koff);
+            const uint32_t h0 = min(max(k0 >> 11, __builtin_elementwise_sub_sat(k0 >> 9, 49152u)), 0xFFFEu);
+            const uint32_t h1 = min(max(k1 >> 11, __builtin_elementwise_sub_sat(k1 >> 9, 49152u)), 0xFFFEu);
             if (FAST) {
                 __builtin_amdgcn_raw_buffer_store_b32(h0 | (h1 << 16), orsrc, 4 * lane, soff, S32_STORE_POLICY);
             } else if (gi < M) {
@@ -343,9 +344,11 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     // two keys of a lane are clamped to 16 bits by the saturating pack, then to 0xFFFE together)
     typedef unsigned short u16x2k __attribute__((ext_vector_type(2)));
     auto keys16 = [&](const float a, const float b) {
-        const u16x2k pk = __builtin_amdgcn_cvt_pk_u16(__builtin_elementwise_sub_sat(__float_as_uint(a), koff) >> 10,
-                                                      __builtin_elementwise_sub_sat(__float_as_uint(b), koff) >> 10);
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(pk, (u16x2k){(unsigned short)0xFFFEu, (unsigned short)0xFFFEu}));
+        const uint32_t ka = __builtin_elementwise_sub_sat(__float_as_uint(a), koff), kb = __builtin_elementwise_sub_sat(__float_as_uint(b), koff);
+        const u16x2k coarse = __builtin_amdgcn_cvt_pk_u16(ka >> 11, kb >> 11);
+        const u16x2k fine = __builtin_amdgcn_cvt_pk_u16(__builtin_elementwise_sub_sat(ka >> 9, 49152u), __builtin_elementwise_sub_sat(kb >> 9, 49152u));
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(coarse, fine),
+                                                                      (u16x2k){(unsigned short)0xFFFEu, (unsigned short)0xFFFEu}));
     };
     auto emit16 = [&](const int t, const int q, const uint32_t cpk, auto fast_tag, auto bw_tag) {
         constexpr bool FAST = decltype(fast_tag)::value;

@@ -335,16 +335,17 @@ def mask_bits_planar32(keys, band, corpus, batch, kappa, mutual=True, out=None, 
 
 
 def keys16_koff(corpus, batch):
-    """Per pair of the batch the uint32 offset of its 16-bit keys (csrc/keys16.h): the float32 bit pattern of 2 W 2^-8, W =
-    the pair's bound on the window norm sums (song_wmax of x + of y; no windowed sum exceeds 2 W) -- key16 =
-    min((bits -sat koff) >> 10, 0xFFFE) then spans the eight octaves below 2 W with 13 mantissa bits.  The pattern is that
-    of the float32 NOT BELOW 2 W (the kernels rely on koff >= 2 W 2^-8).  Device int32 tensor (K)."""
+    """Per pair of the batch the uint32 offset of its 16-bit keys (csrc/keys16.h): the float32 bit pattern of 2 W 2^-7, W =
+    the pair's bound on the window norm sums (song_wmax of x + of y; no windowed sum exceeds 2 W).  With k' = bits -sat koff,
+    key16 = min(max(k' >> 11, (k' >> 9) -sat 49152), 0xFFFE): 14 mantissa bits over the three octaves below 2 W, 12 over the
+    four below those.  The pattern is that of the float32 NOT BELOW 2 W (the kernels rely on koff >= 2 W 2^-7).  Device int32
+    tensor (K)."""
     w = corpus.song_wmax(batch.win)
     sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
     W64 = 2.0 * (w[sx] + w[sy])
     W = W64.astype(np.float32)
     W = np.where(W.astype(np.float64) < W64, np.nextafter(W, np.float32(np.inf)), W).astype(np.float32)
-    bits = W.view(np.uint32).astype(np.int64) - (8 << 23)
+    bits = W.view(np.uint32).astype(np.int64) - (7 << 23)
     koff = np.where(np.isfinite(W) & (W > np.float32(2.0 ** -100)), bits, 0).astype(np.uint32)
     return torch.from_numpy(koff.view(np.int32).copy()).to(corpus.device)
 

@@ -311,13 +311,15 @@ def time_kernel(fn, torch, reps=5):
 
 def pmc_traffic(path, kernel_key, P, frames):
     """HBM bytes per launch of the path's dominant kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE
-    exact, FETCH_SIZE x 2 on gfx950) -- only quoted when the profile was taken on this very workload."""
-    for name in ("r02_%s_pmc.json" % path, "r01_final_pmc.json"):
+    exact, FETCH_SIZE x 2 on gfx950) -- only quoted when the profile was taken on this very workload and path."""
+    for name in ("r03_pmc.json", "r02_%s_pmc.json" % path, "r01_final_pmc.json"):
         f = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(f) or frames != 1000:
             continue
         with open(f) as fh:
             doc = json.load(fh)
+        if name.startswith("r03") and doc.get("_path") != path:
+            continue
         c = doc.get(kernel_key)
         if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
             return (round((c["hbm_write_GB"] + c["hbm_fetch_GB_x2_corrected"]) * 1e9),

@@ -277,9 +277,11 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
                                    void *work, size_t work_bytes, void *stream);
 /* The same filter with 16-bit keys (the default of acoss_serra09_scores since round 3; csrc/keys16.h): the float32 windowed
  * sums of acoss_crp_planar32_batch leave the chip as ONE uint16 per cell,
- *     key16 = min((float32 bits -saturating koff[pair]) >> 10, 0xFFFE),      koff[pair] = bit pattern of W_pair 2^-8
- * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * 16.5 * 2^-24) of `band`):
- * 13 mantissa bits over the eight octaves below W_pair, same element indexing as the uint32 matrix (element = 2 bytes).
+ *     k' = float32 bits -saturating koff[pair],   key16 = min(max(k' >> 11, (k' >> 9) -saturating 49152), 0xFFFE),
+ *     koff[pair] = bit pattern of 2 W_pair 2^-7 (of the float32 not below 2 W_pair)
+ * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * 16.5 * 2^-24) of `band`; no
+ * windowed sum exceeds 2 W_pair): 14 mantissa bits over the three octaves below 2 W_pair, 12 over the four below those, one
+ * monotone map; same element indexing as the uint32 matrix (element = 2 bytes).
  * acoss_mask_bits_keys16_batch selects on those keys; where the winner's error band can reach another key it recomputes
  * the float32 values of the few cells involved from xp / f32 / n32 (the operands acoss_crp_keys16_batch was given, same
  * descriptors) with the strip kernel's arithmetic, and what float32 cannot decide is finished exactly in float64 from

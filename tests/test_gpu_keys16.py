@@ -45,8 +45,9 @@ def _tie_corpus():
 
 
 def test_key_plane_is_the_quantised_float32_matrix(eng, golden):
-    """key16 = min((float32 bits -sat koff) >> 10, 0xFFFE) of exactly the values crp_planar32 writes (same arithmetic in
-    the row-band and the column-strip kernel), for every pitch alignment; koff is the pattern of 2 W 2^-8."""
+    """key16 = min(max(k' >> 11, (k' >> 9) -sat 49152), 0xFFFE), k' = float32 bits -sat koff, of exactly the values
+    crp_planar32 writes (same arithmetic in the row-band and the column-strip kernel), for every pitch alignment; koff is
+    the pattern of 2 W 2^-7."""
     from acoss_amd import synth
     g = golden("pairs_1000")
     lens = iter([9, 40, 65, 129, 300, 1032])
@@ -64,10 +65,11 @@ def test_key_plane_is_the_quantised_float32_matrix(eng, golden):
         w = corpus.song_wmax(9)
         for p in range(batch.K):
             M, N, idx = _cells(batch.descs[p])
-            want = np.minimum(np.maximum(k32[idx] - ko[p], 0) >> 10, 0xFFFE)
+            kp = np.maximum(k32[idx] - ko[p], 0)
+            want = np.minimum(np.maximum(kp >> 11, np.maximum((kp >> 9) - 49152, 0)), 0xFFFE)
             assert np.array_equal(k16[idx], want), (align, p)
             W2 = 2.0 * (w[batch.descs["song_x"][p]] + w[batch.descs["song_y"][p]])
-            top = np.array([ko[p] + (8 << 23)], dtype=np.uint32).view(np.float32)[0]
+            top = np.array([ko[p] + (7 << 23)], dtype=np.uint32).view(np.float32)[0]
             assert W2 <= top <= W2 * (1 + 2.0 ** -22)
 
 

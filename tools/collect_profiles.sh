@@ -1,5 +1,8 @@
 #!/bin/bash
-# Run on the GPU box from the repo root: bench JSON, kernel-trace stats and the PMC passes behind profiles/.
+# Run on the GPU box from the repo root (one gpurun call): the un-profiled bench line, the rocprofv3 --kernel-trace --stats
+# summary of the SAME command line (shortened to 5 steps) and the PMC passes behind profiles/ (each counter set in its own
+# run with --kernel-trace only; FETCH_SIZE and WRITE_SIZE separately).  Results land in gpurun_out/prof_TAG/; copy them
+# into profiles/ with tools/adopt_profiles.py TAG (run in the build container after the merge).
 # usage: tools/collect_profiles.sh TAG [bench args]
 set -o pipefail
 TAG=$1; shift
@@ -8,6 +11,7 @@ O=$R/gpurun_out/prof_$TAG
 mkdir -p $O
 python3 $R/bench.py "$@" > $O/bench.log 2>&1 || exit 1
 grep -E '^\{' $O/bench.log > $O/bench.json
+echo "bench.py $*" > $O/command.txt
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -- python3 $R/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras "$@" > $O/stats.log 2>&1 || exit 2
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/wr -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/wr.log 2>&1 || exit 3
@@ -16,10 +20,8 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_I
 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_SMEM --kernel-trace --output-format csv -d $O/sq2 -- python3 $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extras "$@" > $O/sq2.log 2>&1 || exit 6
 cd $R && python3 tools/pmc_json.py $O/pmc.json $O/wr $O/rd $O/sq $O/sq2 > $O/pmc_table.txt
 cp $O/stats/*/*_kernel_stats.csv $O/kernel_stats.csv
-# one more kernel trace with the side blocks (float64 / fused paths, configs 3-5, scattering CSM): their kernels' durations
+# one more kernel trace with the side blocks (other forms of the filter, configs 3-5, scattering CSM): their kernels' durations
 cd /tmp && rocprofv3 --kernel-trace --stats --output-format csv -d $O/statsx -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > $O/statsx.log 2>&1 || exit 7
 cd $R && cp $O/statsx/*/*_kernel_stats.csv $O/kernel_stats_extras.csv
-rm -rf $O/statsx
-# keep the merge small
-rm -rf $O/stats $O/wr $O/rd $O/sq $O/sq2
+rm -rf $O/statsx $O/stats $O/wr $O/rd $O/sq $O/sq2
 echo done

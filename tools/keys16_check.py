@@ -30,7 +30,8 @@ M0, N0, pitch = int(d0["nx"]) - 8, int(d0["ny"]) - 8, int(d0["crp_pitch"])
 k32 = keys32[int(d0["crp_off"]):int(d0["crp_off"]) + M0 * pitch].cpu().numpy().view(np.uint32).reshape(M0, pitch)[:, :N0] & 0x7fffffff
 k16 = keys16[int(d0["crp_off"]):int(d0["crp_off"]) + M0 * pitch].cpu().numpy().view(np.uint16).reshape(M0, pitch)[:, :N0]
 ko = int(koff[0].item()) & 0xffffffff
-exp = np.minimum(np.maximum(k32.astype(np.int64) - ko, 0) >> 10, 0xFFFE)
+kp = np.maximum(k32.astype(np.int64) - ko, 0)
+exp = np.minimum(np.maximum(kp >> 11, np.maximum((kp >> 9) - 49152, 0)), 0xFFFE)
 print("plane of pair 0 equals the quantised 32-bit keys:", np.array_equal(exp, k16.astype(np.int64)), "key range", k16.min(), k16.max(), flush=True)
 bits16, work16 = engine.mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, 0.095)
 torch.cuda.synchronize()

@@ -21,8 +21,10 @@ for k, c in out.items():
         c["hbm_fetch_GB_x2_corrected"] = 2 * c["FETCH_SIZE"] * 1024 / 1e9
 import os
 out["_pairs_per_step"] = int(os.environ.get("ACOSS_PROFILE_PAIRS", "4096"))
+out["_path"] = os.environ.get("ACOSS_PROFILE_PATH", "fast16")
 json.dump(out, open(sys.argv[1], "w"), indent=1, sort_keys=True)
 out.pop("_pairs_per_step")
+out.pop("_path")
 for k in sorted(out):
     c = out[k]
     print("%-50s %9.1f us  W %.3f GB  R(x2) %.3f GB  vgpr %d" % (k, c["avg_us_under_pmc"], c.get("hbm_write_GB", float("nan")), c.get("hbm_fetch_GB_x2_corrected", float("nan")), c["vgpr"]))

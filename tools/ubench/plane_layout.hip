@@ -172,6 +172,38 @@ __global__ __launch_bounds__(512) void cols_k(const unsigned char *in, unsigned 
     if (acc == 0x12345u) sink[0] = acc;
 }
 
+
+// ---- column tile reads again, under the occupancy of the real column kernel (LDS sized for three blocks per CU) and with a
+// TILED plane: tiles of 64 rows x 64 cells (8 KB), so that the 1024 row segments a block fetches lie in 16 tiles instead of
+// 1024 different 2 KB rows (TLB reach, DRAM page locality)
+// MODE 0: row-major u16 plane, pitch 2048 B    MODE 1: tiled plane
+template <int MODE>
+__global__ __launch_bounds__(512) void cols2_k(const unsigned char *in, unsigned *sink, int col_blocks)
+{
+    __shared__ unsigned pad[12800];          // 51 KB: three blocks per CU
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    const int p = lb / col_blocks, cb = lb % col_blocks;
+    const unsigned char *base = in + (size_t)p * M * 4096;
+    unsigned acc = 0;
+    const int c2 = threadIdx.x & 7, rp = threadIdx.x >> 3;
+#pragma unroll
+    for (int s = 0; s < 8; s++) {
+#pragma unroll
+        for (int z = 0; z < 2; z++) {
+            const int row = min(128 * s + 2 * rp + z, M - 1);
+            size_t off;
+            if (MODE == 0) off = (size_t)row * 2048 + cb * 64 + c2 * 8;
+            else off = ((size_t)(row >> 6) * 16 + (cb >> 1)) * 8192 + (row & 63) * 128 + (cb & 1) * 64 + c2 * 8;
+            const u32x2 v = *(const u32x2 *)(base + off);
+            acc += v.x + v.y;
+        }
+    }
+    pad[threadIdx.x] = acc;
+    __syncthreads();
+    acc = pad[(threadIdx.x * 7) & 511];
+    if (acc == 0x12345u) sink[0] = acc;
+}
+
 template <typename F>
 static float timed(F f)
 {
@@ -234,5 +266,9 @@ int main(int argc, char **argv)
     CL(0, 62, 4, "u32 cells, 16 columns (64 B segments) [today]")
     CL(1, 31, 2, "u16 plane, 32 columns (64 B segments)")
     CL(2, 62, 2, "u16 plane, 16 columns (32 B segments)")
+#define CL2(MODE, name) t = timed([&] { cols2_k<MODE><<<K * 31, 512>>>(buf, sink, 31); }); \
+    printf("cols2 %-57s %.3f ms  %.2f TB/s\n", name, t, cells * 2 / t / 1e9);
+    CL2(0, "u16 plane row-major, 32 columns, 3 blocks / CU")
+    CL2(1, "u16 plane in 64 x 64 tiles, 32 columns, 3 blocks / CU")
     return 0;
 }
