@@ -348,16 +348,20 @@ extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float 
 #endif
     const int rb = ceil_div(max_m, 4 * K16_ROWS_PER_WAVE), cb = ceil_div(max_n, K16_COLS);
     if ((int64_t)K * rb > 0x7fffffffLL || (int64_t)K * cb > 0x7fffffffLL) { set_error("mask_bits_keys16_batch: batch too large"); return ACOSS_ENOTSUP; }
-    if (d == 12) hipLaunchKernelGGL(select_rows_k16_kernel<12>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
-    else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
-    int rc = launch_check("select_rows_k16_kernel");
-    if (rc) return rc;
+    int rc = ACOSS_OK;
+    if (mutual != 3) {                          // (3 = measurement: the column selection kernel alone)
+        if (d == 12) hipLaunchKernelGGL(select_rows_k16_kernel<12>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
+        else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
+        rc = launch_check("select_rows_k16_kernel");
+        if (rc) return rc;
+    }
     if (mutual == 2) return ACOSS_OK;           // measurement: the row selection kernel alone (bench.py's roofline_selection)
     if (mutual) {
         if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
         else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
         rc = launch_check("select_cols_k16_kernel");
         if (rc) return rc;
+        if (mutual == 3) return ACOSS_OK;
     }
     hipLaunchKernelGGL(select_fix_side16_kernel, dim3((unsigned)w.side_cap), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
     rc = launch_check("select_fix_side16_kernel");

@@ -373,7 +373,7 @@ def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True
         work = torch.empty(need, dtype=torch.uint8, device=keys16.device)
     check(lib.acoss_mask_bits_keys16_batch(_ptr(keys16), _ptr(band), _ptr(koff), _ptr(xp32), _ptr(f32), _ptr(n32), _ptr(corpus.feats),
                                            _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
-                                           batch.max_ny, float(kappa), 2 if mutual == "rows_kernel_only" else int(bool(mutual)), _ptr(out), _ptr(work),
+                                           batch.max_ny, float(kappa), {"rows_kernel_only": 2, "cols_kernel_only": 3}.get(mutual) if isinstance(mutual, str) else int(bool(mutual)), _ptr(out), _ptr(work),
                                            work.numel(), _stream()), "mask_bits_keys16_batch")
     return out, work
 

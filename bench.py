@@ -781,18 +781,33 @@ def main():
             # live with HIP events: rows = the row kernel alone (fast16; for fast32 the non-mutual call, which also holds the
             # refinement and the combine kernel), cols = mutual call minus non-mutual call
             cellb = 2.0 if args.path == "fast16" else 4.0
+            t_rowk = t_colk = None
             if args.path == "fast16":
                 planes = runner.S.view(torch.int16)[:engine.planar_elems(b) + 64]
-                engine.crp_keys16(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), runner.koffs[-1], out=planes)
+                strip = lambda: engine.crp_keys16(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), runner.koffs[-1], out=planes)
                 sel = lambda mutual: engine.mask_bits_keys16(planes, runner.bands[-1], runner.koffs[-1], runner.xp, corpus, b, kappa, mutual,
                                                              out=runner.bits, work=runner.work)
-                t_rowk = time_kernel(lambda: sel("rows_kernel_only"), torch)
+                # each selection kernel alone, but where it runs in the chain: right behind the strip kernel (rows) and behind
+                # the row kernel (columns) -- repeated in isolation the row kernel is ~10 % faster than in the chain
+                rk, ck = [], []
+                for rep in range(5):
+                    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+                    strip()
+                    ev[0].record()
+                    sel("rows_kernel_only")
+                    ev[1].record()
+                    sel("cols_kernel_only")
+                    ev[2].record()
+                    torch.cuda.synchronize()
+                    if rep:
+                        rk.append(ev[0].elapsed_time(ev[1]))
+                        ck.append(ev[1].elapsed_time(ev[2]))
+                t_rowk, t_colk = float(np.median(rk)), float(np.median(ck))
                 rname, cname = "select_rows_k16_kernel<12>", "select_cols_k16_kernel<12>"
             else:
                 planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
                 engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
                 sel = lambda mutual: engine.mask_bits_planar32(planes, runner.bands[-1], corpus, b, kappa, mutual, out=runner.bits, work=runner.work)
-                t_rowk = None
                 rname, cname = "select_rows_planar_kernel<0, 16>", "select_cols_planar_kernel<0>"
             t_rows = time_kernel(lambda: sel(False), torch)
             t_both = time_kernel(lambda: sel(True), torch)
@@ -803,8 +818,11 @@ def main():
                         "achieved": round(kb / ms / 1e6, 1), "frac": round(kb / ms / 1e6 / HBM_PEAK_GBS, 4), "measured": note}
             out["roofline_selection"] = {
                 "rows": blk(rname, t_rowk if t_rowk is not None else t_rows,
-                            "HIP events around the kernel alone" if t_rowk is not None else "HIP events around the non-mutual call (rows + refinement + combine)"),
-                "cols": blk(cname, t_both - t_rows, "HIP events: mutual call minus non-mutual call"),
+                            "HIP events around the kernel alone, launched right behind the strip kernel as in the chain" if t_rowk is not None
+                            else "HIP events around the non-mutual call (rows + refinement + combine)"),
+                "cols": blk(cname, t_colk if t_colk is not None else t_both - t_rows,
+                            "HIP events around the kernel alone, launched right behind the row kernel as in the chain" if t_colk is not None
+                            else "HIP events: mutual call minus non-mutual call"),
                 "rows_call_ms": round(t_rows, 4), "both_call_ms": round(t_both, 4),
                 "note": "each kernel reads the key matrix once, %d B / cell; both are bound by instruction issue and, for the columns, the "
                         "LDS staging round trip rather than by HBM (DESIGN.md section 4b)" % int(cellb)}

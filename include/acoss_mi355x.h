@@ -287,8 +287,8 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
  * descriptors) with the strip kernel's arithmetic, and what float32 cannot decide is finished exactly in float64 from
  * feats / norms as in acoss_mask_bits_planar32_batch.  Masks identical to acoss_mask_bits_batch on the float64 sums.
  * CRPUtils.py:67-84 + :24-45 + :169-219; d in {12, 13}, win == 9, matrices up to 1024 x 1024; work / bits sizes as for
- * acoss_mask_bits_batch.  (mutual == 2 launches the row selection kernel alone and leaves `bits` untouched: a measurement
- * hook for bench.py's per-kernel rooflines.) */
+ * acoss_mask_bits_batch.  (mutual == 2 / 3 launch the row / the column selection kernel alone and leave `bits` untouched:
+ * measurement hooks for bench.py's per-kernel rooflines.) */
 int acoss_crp_keys16_batch(const float *xp, const float *feats, const float *norms, int d, const acoss_pair_desc *descs,
                            int K, int win, int max_nx, int max_ny, const uint32_t *koff, uint16_t *out, void *stream);
 int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
