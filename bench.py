@@ -17,15 +17,21 @@ Without a launcher (`WORLD_SIZE` unset) and N > 1 the parent process starts the 
 torch.distributed.run, before anything touches the GPU.  A `--gpus` that disagrees with the launcher's world size is
 an error.
 
-Prints ONE JSON line on rank 0.  `roofline` describes the dominant HBM-bound kernel of the timed path -- the
-cross-similarity + sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region
-(`stage_ms` has every stage).  Beside the headline (rank 0, one GPU; `--no-extras` skips them):
-`roofline_csm_*` = the stand-alone get_csm kernels; `roofline_selection` = the row and column selection kernels' read rates; `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores
-and whether the GPU scores of the sampled pairs are identical; `f64_path` = the same steps with every windowed sum in
-float64 (scores must be identical); `fused` = the same steps with the masks from the fused band kernel; `plugin` = pairs/s
-through the one-call scorer (`engine.serra09_scores`); `config3`, `early_snf`, `ftm2d` = BASELINE configs 3-5 on small
-samples, each with the oracle's CPU rate and an identity check; `scatter_csm` = the float32 992 x 20736 x 992 CSM of the
-scattering features (Serra09.py:187-192) on the matrix cores.
+Prints ONE JSON line on rank 0.  `roofline` describes the strip kernel of the timed path -- the cross-similarity +
+sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region (`stage_ms` has every stage);
+`roofline_selection.rows` / `.cols` the two selection kernels that read its output, each launched alone where it runs in the
+chain.  Beside each live block: the same kernel's average in the committed rocprofv3 summary (`profiles_avg_launch_ms`,
+`profiles_frac`), when profiles/r03_profile_meta.json names this workload.  The key matrix lives in a plain allocation
+(`placement_scanned` = the same steps after a scan of arena windows; ACOSS_BENCH_ARENA_GB=<n> makes the scan the headline's).
+Beside the headline (rank 0, one GPU; `--no-extras` skips them): `roofline_csm_*` = the stand-alone get_csm kernels;
+`cpu_baseline` / `parity` = the CPU oracle's chain on the host cores and whether the GPU scores of the sampled pairs are
+identical (also on N > 1 lines); `keys32_path` / `f64_path` / `fused` = the same steps with 32-bit keys, with every windowed sum
+in float64, with the masks from the fused band kernel (scores must be identical); `plugin` = pairs/s through the one-call C
+scorer; `full_job` = the whole 499 500-pair job through Serra09.all_pairwise + getEvalStatistics with MAP, and the 64-song slice
+against the reference's own scores and statistics ("MAP vs ref" of BASELINE.json:metric); `plugin_similarity` =
+Serra09.similarity as the reference's drivers call it (chroma + MFCC, qmax + dmax each); `scatter_chain` / `scatter_csm` = the
+float32 20 736-d scattering-feature chain and its CSM on the matrix cores (Serra09.py:187-192); `config3`, `early_snf`, `ftm2d`
+= BASELINE configs 3-5 on small samples, each with the oracle's CPU rate and an identity check.
 """
 import argparse
 import json
