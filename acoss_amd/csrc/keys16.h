@@ -110,7 +110,7 @@ __device__ inline float k16_c_value(const float *__restrict__ xrow0, const float
 // common path.
 __device__ inline void k16_reach(unsigned th, unsigned koff, const float *pair_band, unsigned &h_lo, unsigned &h_hi)
 {
-    if (th > K16_FINE && th < K16_MAX) {
+    if (koff != 0u && th > K16_FINE && th < K16_MAX) {       // (koff == 0: a pair too quiet for the window to mean anything)
         h_lo = th - 1u;
         h_hi = min(th + 1u, K16_MAX);
         return;

@@ -190,3 +190,34 @@ def test_scale_free(eng, orc):
             q, d = orc.serra09_pair(feats[ch.frame_off[i]:ch.frame_off[i + 1]], ch.gchroma[i],
                                     feats[ch.frame_off[j]:ch.frame_off[j + 1]], ch.gchroma[j])
             assert got["qmax"][t] == q and got["dmax"][t] == d, (mag, t)
+
+
+def test_pairs_far_below_the_corpus_scale(eng):
+    """Two songs 1e-20 of the loudness of the rest of the corpus: after the centring of the float32 copy their frames are
+    almost constant vectors with ordinary norms, so their windowed sums cancel catastrophically in float32 (every key of
+    the quiet pair clamps to 0 or carries no information) and everything is decided by the exact refinement; pairs mixing
+    them with ordinary songs too (rows of equal values up to the last bits of float64: exact ties, cut lowest position
+    first).  Masks equal the float64 kernels' (the oracle forms its window sums by cumulative differences and breaks such
+    ties differently: section 3 of DESIGN.md)."""
+    import torch
+    from acoss_amd import synth
+    lens = iter([240, 300, 210, 280])
+    ch = synth.make_corpus(2, 2, seed=33, lengths=lambda r: next(lens))
+    feats = ch.feats.copy()
+    off = ch.frame_off
+    for s_ in (1, 3):
+        feats[off[s_]:off[s_ + 1]] *= 1e-20
+    corpus = eng.DeviceCorpus(feats, off, gchroma=ch.gchroma)
+    pairs = np.array([(1, 3), (3, 1), (0, 1), (3, 2), (0, 2), (1, 1)], dtype=np.int32)
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    xp32, koff, band, k16 = _chain(eng, corpus, batch)
+    for mutual in (True, False):
+        want, _ = eng.mask_bits(T, batch, 0.095, mutual=mutual)
+        got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, mutual=mutual)
+        for p in range(batch.K):
+            assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (mutual, p)
+    a = eng.serra09_scores(corpus, pairs)
+    b = eng.serra09_scores(corpus, pairs, approx32=False)
+    assert np.array_equal(a["qmax"], b["qmax"]) and np.array_equal(a["dmax"], b["dmax"])
