@@ -43,7 +43,9 @@ __device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, i
     return true;
 }
 
-constexpr int K16_ROWS_PER_WAVE = 16;
+// A pair's rows are dealt evenly over the 4 * rows_blocks waves the grid gives it (rows_blocks covers max_m at up to
+// K16_ROWS_PER_WAVE rows per wave): equal wave loads for every song length, and long runs of rows inside one predicted window.
+constexpr int K16_ROWS_PER_WAVE = 32;
 #ifndef K16_ROWS_WPS
 #define K16_ROWS_WPS 8
 #endif
@@ -57,11 +59,12 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int p = lb / rows_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int r0 = ((lb % rows_blocks) * 4 + wave) * K16_ROWS_PER_WAVE;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    const int rpw = (M + 4 * rows_blocks - 1) / (4 * rows_blocks);
+    const int r0 = ((lb % rows_blocks) * 4 + wave) * rpw;
     if (r0 >= M) return;
-    const int r1 = min(r0 + K16_ROWS_PER_WAVE, M);
+    const int r1 = min(r0 + rpw, M);
     const int lane = threadIdx.x & 63;
     const int k = knn_count(k_mode, kv, N);
     unsigned *hist = hist_all + wave * K16_HIST_WORDS;
