@@ -231,7 +231,10 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     constexpr int KSTEPS = (D + 3) / 4;
     __shared__ __attribute__((aligned(16))) float cbuf_raw[R32_CR * R32_LD + 2 * S32_CPAD + 1];
     // the band's x frames as matrix-core operands: row r, lane group lk -> the four floats [bin lk, bin 4 + lk, bin 8 + lk,
-    // bin 12 + lk] (one 16-byte read per tile hands a lane its operand of every contraction step), and their squared norms
+    // bin 12 + lk] (one 16-byte read per tile hands a lane its operand of every contraction step), and their squared norms.
+    // Laid out [tile][lk][row in tile]: the 16-byte unit a lane reads is unit `lane` of its tile, the one image every lane
+    // group of ds_read_b128 takes without bank conflicts ([row][lk] made each group of 16 lanes hit 4 x 4 banks: 16 LDS
+    // cycles per read instead of 4)
     __shared__ __attribute__((aligned(16))) float xa[R32_CR * 16];
     __shared__ __attribute__((aligned(16))) float xn[R32_CR];
     float *const cbuf = cbuf_raw + S32_CPAD;
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         for (int i = 0; i < 4; i++) {
             const int e = 4 * c + i;              // position in the packed line; (e & 3) == i
             if (e == D) xn[r] = e4[i];
-            xa[r * 16 + i * 4 + c] = e < D ? e4[i] : 0.0f;      // bin e = 4 c + i: group i, step c
+            xa[(((r >> 4) * 4 + i) * 16 + (r & 15)) * 4 + c] = e < D ? e4[i] : 0.0f;      // bin e = 4 c + i: group i, step c
         }
     }
     // chunks: until every output column (< ny - 8) has left the lanes that hold real sums: a row's last block takes its
@@ -288,8 +291,9 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
     const uint32_t koff = OUT == 1 ? koff_of[p] : 0u;
     const int bw = wave & 1;                 // odd waves sit one column to the right (see above)
     float *const wr = cbuf + (4 * lk) * R32_LD + R32_CARRY + 16 * wave + lr;
-    const float *const rdd = cbuf + (wave * R32_RPW) * R32_LD + bw + 2 * lane;
-    const v4f32 *const xa_rd = reinterpret_cast<const v4f32 *>(xa) + lr * 4 + lk;         // + 64 per row tile
+    // (LDS byte address of the lane's first diagonal read: cbuf + (7 wave) rows + bw + 2 lane)
+    const unsigned rdd_lds = (unsigned)(uintptr_t)(cbuf + (wave * R32_RPW) * R32_LD + bw + 2 * lane);
+    const v4f32 *const xa_rd = reinterpret_cast<const v4f32 *>(xa) + lane;                // + 64 per row tile
     const v4f32 *const xn_rd = reinterpret_cast<const v4f32 *>(xn) + lk;                  // + 4 per row tile
     // carry: columns [128, 143) of all 64 rows -> [0, 15): 960 floats, two per thread for the first 480 threads
     const int ce0 = 2 * tid, ce1 = 2 * tid + 1;
@@ -409,15 +413,21 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         }
         lds_barrier();
         // ---- rows 7w .. 7w+6 of the band: window sums along the lane's two diagonals
-        v2f32 v[R32_RPW + S32_HALO];
-#pragma unroll
-        for (int m = 0; m < R32_RPW + S32_HALO; m++) v[m] = *reinterpret_cast<const v2f32 *>(rdd + m * (R32_LD + 1));
         // carry the chunk's last 15 columns: read before the barrier, write after it
         float k0 = 0.f, k1 = 0.f;
         if (carrier) {
             k0 = cbuf[cr0 * R32_LD + R32_CW + cc0];
             k1 = cbuf[cr1 * R32_LD + R32_CW + cc1];
         }
+        // fifteen single ds_read_b64 (2 LDS cycles each: two groups of 32 lanes over 64 banks); left to the compiler they
+        // pair up into ds_read2_b64, which the LDS serves as two 4 x 16-lane accesses: 8 cycles per pair
+        v2f32 v[R32_RPW + S32_HALO];
+#pragma unroll
+        for (int m = 0; m < R32_RPW + S32_HALO; m++)
+            asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(v[m]) : "v"(rdd_lds), "n"(m * (R32_LD + 1) * 4) : "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
+                       "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(k0), "+v"(k1));
 #pragma unroll
         for (int q = 0; q < R32_RPW; q++) {
             v2f32 s = v[q];
