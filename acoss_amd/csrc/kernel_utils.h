@@ -56,5 +56,20 @@ __device__ inline double csm_sqrt(double c)
 }
 __device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
 
+// The float32 window sum T~ of output row i, as every float32 kernel forms it (strip32_kernels.hip; the recomputation in
+// keys16.h): nine non-negative C values of one diagonal, c[k] = C[i + k][j + k], added pairwise (depth 4: the bound
+// 9.5 u T of engine.PLANAR32_BOUND_T covers it with room to spare).  The association depends on the row,
+// odd = (i mod 7) & 1: a wave of the row-band kernel forms seven consecutive rows from fifteen C values of a diagonal
+// and shares the partial sums between neighbouring rows (24 additions for seven sums; summing each window on its own: 56).
+//     even rows:  c0 + (((c1 + c2) + (c3 + c4)) + ((c5 + c6) + (c7 + c8)))
+//     odd rows:   (((c0 + c1) + (c2 + c3)) + ((c4 + c5) + (c6 + c7))) + c8
+template <typename T>
+__device__ inline T window_sum9(const T *c, bool odd)
+{
+    if (odd) return (((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]))) + c[8];
+    return c[0] + (((c[1] + c[2]) + (c[3] + c[4])) + ((c[5] + c[6]) + (c[7] + c[8])));
+}
+__device__ inline bool window_sum9_odd(int row) { return (((row % 7) + 7) % 7) & 1; }
+
 
 }  // namespace acoss

@@ -20,7 +20,7 @@
 //     benchmark corpus): the masks follow from key16 <= threshold alone;
 //  2. otherwise the few cells in that range (two or three) get their float32 value RECOMPUTED from the features by the
 //     selecting wave, one cell per lane, with the strip kernel's arithmetic bit for bit (an FMA chain over the bins, the nine
-//     terms added in window order: tests/test_gpu_fast_path.py pins the matrix-core form against exactly this chain) -- the
+//     terms added by window_sum9(): tests/test_gpu_fast_path.py pins the matrix-core form against exactly this chain) -- the
 //     full 32-bit keys of those cells then decide as the 32-bit selection does;
 //  3. if the winner is still not alone in its error band (2 %), or the threshold clamps: the row's keys go to the side buffer
 //     and select_fix_side16_kernel finishes it in float64 (exact values of every cell in the reachable range).
@@ -76,7 +76,7 @@ struct K16Ctx {
 };
 
 // C[i][j] of T~ exactly as the strip kernels form it (strip32_kernels.hip): dot = FMA chain over the bins of the rolled x
-// frame, C = max(fma(-2, dot, |x|^2 + |y|^2), 0); the nine C values of a window are then added in window order
+// frame, C = max(fma(-2, dot, |x|^2 + |y|^2), 0); the nine C values of a window are then added by window_sum9()
 template <int D>
 __device__ inline float k16_c_value(const float *__restrict__ xrow0, const float *__restrict__ f32, const float *__restrict__ n32,
                                     const acoss_pair_desc &ds, int i, int j)
@@ -347,7 +347,7 @@ __device__ inline int k16_decide(const u16x2 (&h)[8], const Sel16 &s, int k, uns
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     // seven cells at a time: lane (g, kk) forms C[i + kk][j + kk] of cell g (all of the wave's loads in flight at once), lane g
-    // adds the nine values in window order
+    // adds the nine values as the strip kernel does (window_sum9 of kernel_utils.h: the association follows the row)
     const float *xrow0 = cx.xp + (int64_t)p * cx.max_nx * 16;
     for (int c0 = 0; c0 < total; c0 += 7) {
         const int g = lane / 9, kk = lane - 9 * g, el = c0 + g;
@@ -358,10 +358,14 @@ __device__ inline int k16_decide(const u16x2 (&h)[8], const Sel16 &s, int k, uns
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (lane < 7 && c0 + lane < total) {
-            float sum = __uint_as_float(scratch[64 + 9 * lane]);
+            float cv[9];
 #pragma unroll
-            for (int q = 1; q < 9; q++) sum += __uint_as_float(scratch[64 + 9 * lane + q]);
-            scratch[128 + c0 + lane] = __float_as_uint(fabsf(sum));
+            for (int q = 0; q < 9; q++) cv[q] = __uint_as_float(scratch[64 + 9 * lane + q]);
+            const int row = DIR == 0 ? which : (int)scratch[c0 + lane];
+            const bool odd = window_sum9_odd(row);
+            // (both associations, one select: no divergent branch)
+            const float se = window_sum9(cv, false), so = window_sum9(cv, true);
+            scratch[128 + c0 + lane] = __float_as_uint(fabsf(odd ? so : se));
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }

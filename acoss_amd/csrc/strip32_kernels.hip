@@ -14,7 +14,7 @@
 //
 // Same decomposition as the float64 kernel: a persistent 8-wave block per 120-column strip of a pair walks down in
 // 32-row steps; C rows on the matrix cores into LDS, window sums by diagonal runs (a lane walks two adjacent
-// diagonals for 4 rows: 12 aligned 8-byte LDS reads, every output summed in the order k = 0..8), one 8-byte store per
+// diagonals for 4 rows: 12 aligned 8-byte LDS reads, every output = window_sum9() of kernel_utils.h), one 8-byte store per
 // lane and row through a raw buffer resource.
 #include "common.h"
 #include "kernel_utils.h"
@@ -149,9 +149,7 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
 #pragma unroll
         for (int q = 0; q < S32_RPW; q++) {
             const int gi = g0 + q;
-            v2f32 s = v[q];
-#pragma unroll
-            for (int k = 1; k < S32_WIN; k++) s += v[q + k];
+            const v2f32 s = window_sum9(&v[q], window_sum9_odd(gi));        // (wave-uniform branch)
             const int col = dcol + q;
             const int soff = 4 * (orow0 + (t * S32_ROWS + q) * ds.crp_pitch);
             const uint32_t ha = __float_as_uint(s.x) | 0x80000000u, hb = __float_as_uint(s.y) | 0x80000000u;
@@ -201,9 +199,9 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
 //
 // Per chunk: C[64][128] on the matrix cores into LDS (wave w: columns 16w .. 16w+15, four 16-row tiles; the y fragments
 // of the next chunk are already in flight), LDS-only barrier, then wave w forms rows 7w .. 7w+6 of the band: a lane walks
-// two adjacent diagonals down 7 rows (15 aligned 8-byte LDS reads for 14 outputs), every output summed in the order
-// k = 0..8 -- the arithmetic of crp_strip32_kernel cell for cell (tests/test_gpu_fast_path.py pins both against the host
-// emulation).  Walking diagonals, the columns a lane holds drift by one per row, so row q of a chunk covers columns
+// two adjacent diagonals down 7 rows (15 single 8-byte LDS reads for 14 outputs); the seven window sums share their partial
+// sums (24 packed additions; window_sum9() of kernel_utils.h defines the association) -- the arithmetic of
+// crp_strip32_kernel cell for cell (tests/test_gpu_fast_path.py pins both against the host emulation).  Walking diagonals, the columns a lane holds drift by one per row, so row q of a chunk covers columns
 // [A + q, A + q + 128) with A = 128 t - 15 (+ 1 in odd waves: 8-byte alignment of the diagonal reads).  Stores must be
 // line-aligned (the same pieces shifted by a few cells store at half the rate), so each row is brought into place in
 // registers: the aligned block [128 (t-1), 128 t) of a row is the tail of what the previous chunk produced (kept in two
@@ -428,11 +426,32 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         asm volatile("s_waitcnt lgkmcnt(0)"
                      : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]),
                        "+v"(v[9]), "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(k0), "+v"(k1));
+        // window sums of the wave's seven rows (row R0 + 7 wave + q: q = row mod 7, bands start at multiples of 56) with shared
+        // partial sums: exactly window_sum9(&v[q], q & 1) of kernel_utils.h, in 24 packed additions instead of 56
+        v2f32 ws[R32_RPW];
+        {
+            const v2f32 p1 = v[1] + v[2], p3 = v[3] + v[4], p5 = v[5] + v[6], p7 = v[7] + v[8];
+            const v2f32 q1 = p1 + p3, q5 = p5 + p7;
+            const v2f32 m0 = q1 + q5;
+            ws[0] = v[0] + m0;
+            ws[1] = m0 + v[9];
+            const v2f32 p9 = v[9] + v[10];
+            const v2f32 q3 = p3 + p5, q7 = p7 + p9;
+            const v2f32 m2 = q3 + q7;
+            ws[2] = v[2] + m2;
+            ws[3] = m2 + v[11];
+            const v2f32 p11 = v[11] + v[12];
+            const v2f32 q9 = p9 + p11;
+            const v2f32 m4 = q5 + q9;
+            ws[4] = v[4] + m4;
+            ws[5] = m4 + v[13];
+            const v2f32 p13 = v[13] + v[14];
+            const v2f32 q11 = p11 + p13;
+            ws[6] = v[6] + (q7 + q11);
+        }
 #pragma unroll
         for (int q = 0; q < R32_RPW; q++) {
-            v2f32 s = v[q];
-#pragma unroll
-            for (int k = 1; k < S32_WIN; k++) s += v[q + k];
+            const v2f32 s = ws[q];
             if constexpr (OUT == 1) {
                 const uint32_t cpk = keys16(s.x, s.y);
                 if (t > 0) emit16(t, q, cpk, fast_tag, bw_tag);

@@ -453,11 +453,11 @@ def test_float32_filter_with_useless_approximation(eng):
                 assert np.array_equal(eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)), (do_oti, mutual, p)
 
 
-def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng):
+def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng, monkeypatch):
     """The error bound of the float32 filter assumes that v_mfma_f32_16x16x4_f32 accumulates like a chain of
     round-to-nearest FMAs over k (as the float64 form does).  Pinned here bit for bit: the kernel's keys equal a host
     emulation of its arithmetic in float32 (an FMA = one rounding of the exact product-sum; the product of two float32
-    is exact in float64)."""
+    is exact in float64), window sums included (pairwise, shared between the rows of a wave: kernel_utils.h)."""
     from acoss_amd import synth
     lens = iter([200, 150, 173])
     ch = synth.make_corpus(3, 1, seed=5, lengths=lambda r: next(lens))
@@ -465,7 +465,11 @@ def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng):
     pairs = np.array([(0, 1), (1, 2), (2, 0)], dtype=np.int32)
     b = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
     eng.oti(corpus, b)
-    keys = eng.crp_planar32(corpus, b, eng.pack_x32(corpus, b)).cpu().numpy().view(np.uint32)
+    xp32 = eng.pack_x32(corpus, b)
+    keys = eng.crp_planar32(corpus, b, xp32).cpu().numpy().view(np.uint32)
+    monkeypatch.setenv("ACOSS_STRIP32_FORM", "cols")          # the column-strip kernel of round 2: the same keys, cell for cell
+    keys_cols = eng.crp_planar32(corpus, b, xp32).cpu().numpy().view(np.uint32)
+    monkeypatch.delenv("ACOSS_STRIP32_FORM")
     f32, n32 = [t.cpu().numpy() for t in eng.float32_copy(corpus)]
     shifts = b.descs_dev.cpu().numpy().view(eng.PAIR_DESC)["shift"]
 
@@ -482,11 +486,15 @@ def test_float32_strip_kernel_is_a_round_to_nearest_fma_chain(eng):
         nsum = (n32[int(d["x_row0"]):int(d["x_row0"]) + nx][:, None] + n32[int(d["y_row0"]):int(d["y_row0"]) + ny][None, :]).astype(np.float32)
         C = np.maximum(fma32(np.full_like(acc, -2.0), acc, nsum), np.float32(0))
         M, N = nx - 8, ny - 8
-        T = C[0:M, 0:N].copy()
-        for k in range(1, 9):
-            T = (T + C[k:k + M, k:k + N]).astype(np.float32)
+        # window sums as window_sum9() of csrc/kernel_utils.h associates them: by the row, (i mod 7) & 1
+        c = [C[k:k + M, k:k + N] for k in range(9)]
+        even = c[0] + (((c[1] + c[2]) + (c[3] + c[4])) + ((c[5] + c[6]) + (c[7] + c[8])))
+        odd = (((c[0] + c[1]) + (c[2] + c[3])) + ((c[4] + c[5]) + (c[6] + c[7]))) + c[8]
+        assert even.dtype == np.float32 and odd.dtype == np.float32
+        T = np.where((((np.arange(M) % 7) & 1) == 1)[:, None], odd, even)
         idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
         assert np.array_equal(keys[idx] & 0x7fffffff, T.view(np.uint32)), p
+        assert np.array_equal(keys_cols[idx], keys[idx]), p
 
 
 def test_float32_filter_is_scale_free(eng, orc):
