@@ -116,6 +116,9 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
         if (lane == 0) w.row_cut[(int64_t)p * w.max_m + i] = state == K16_DECIDED ? 0x7fffffff : -3;
         if (state == K16_DECIDED) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sel, brsrc, 2 * lane, i * 128, 0);
     }
+    // a hint for the column kernel, which starts every wave cold: the last threshold key of the pair's first rows (the low
+    // word of a slot that only an unresolved column 0 ever uses, and then with a zero low word = no hint)
+    if (lane == 0 && r0 == 0 && warm.hi != 0u) reinterpret_cast<unsigned *>(w.col_thr + (int64_t)p * w.max_n)[0] = warm.hi;
 }
 
 // ---- columns ---------------------------------------------------------------------------------------------------------------
@@ -126,10 +129,16 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
 // writes (column stride 265 words = 9 banks ... 1 mod 8 with the four columns of a thread, u = 0..3 across the 32 lanes of a
 // write) are conflict-free.
 constexpr int K16_COLS = 32;
+#ifndef K16_COL_SEED
+#define K16_COL_SEED 1
+#endif
+#ifndef K16_COL_SEED_WIDEN
+#define K16_COL_SEED_WIDEN 2              // log2: the first window of a wave is this much wider than K16_SHIFT0's
+#endif
 constexpr int K16_LDC = 265;            // words per staged half column: 8 x 33 + 1
 
 template <int D>
-__global__ __launch_bounds__(512, 4) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+__global__ __launch_bounds__(512, 6) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                                  int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx)
 {
     __shared__ __attribute__((aligned(16))) unsigned colbuf[K16_COLS * K16_LDC + 8];
@@ -207,7 +216,9 @@ __global__ __launch_bounds__(512, 4) void select_cols_k16_kernel(const uint16_t 
     hist256_clear(hist, lane);
     hist[HIST256_BINS + 64 + 192 + lane] = 0u;
     const int k = knn_count(k_mode, kv, M);
-    HistWarm warm{0, K16_SHIFT0};
+    // first window: around the row kernel's hint, wider than between neighbouring columns
+    HistWarm warm{K16_COL_SEED ? reinterpret_cast<const unsigned *>(w.col_thr + (int64_t)p * w.max_n)[0] : 0u, K16_SHIFT0 + K16_COL_SEED_WIDEN};
+    if (warm.hi >= K16_MAX) warm.hi = 0u;
     const unsigned koff = cx.koff[p];
     const float *pair_band = w.band + 2 * p;
     auto column = [&](const u16x2 (&h)[8], const int j) {
@@ -238,8 +249,10 @@ __global__ __launch_bounds__(512, 4) void select_cols_k16_kernel(const uint16_t 
         if (state == K16_DECIDED) reinterpret_cast<uint16_t *>(w.col_word(p, j, lane >> 2))[lane & 3] = (uint16_t)sel;
     };
 #pragma unroll
-    for (int c = 0; c < 4; c++)
+    for (int c = 0; c < 4; c++) {
         if (ja + c < N) column(hc[c], ja + c);
+        if (c == 0) warm.shift = K16_SHIFT0;       // neighbouring columns predict each other closely
+    }
 }
 
 // ---- refinement ------------------------------------------------------------------------------------------------------------
