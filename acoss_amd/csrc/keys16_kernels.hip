@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
 // packed rows (16 l + 2 u, 16 l + 2 u + 1) of lane l at word 33 u + (l & 31): reads (u fixed, lanes consecutive) and
 // writes (column stride 265 words = 9 banks ... 1 mod 8 with the four columns of a thread, u = 0..3 across the 32 lanes of a
 // write) are conflict-free.
-constexpr int K16_COLS = 32;
+#ifndef K16_COL_WAVES
+#define K16_COL_WAVES 8                   // waves per block, four columns each
+#endif
+constexpr int K16_COLS = 4 * K16_COL_WAVES;
 #ifndef K16_COL_SEED
 #define K16_COL_SEED 1
 #endif
@@ -138,11 +141,11 @@ constexpr int K16_COLS = 32;
 constexpr int K16_LDC = 265;            // words per staged half column: 8 x 33 + 1
 
 template <int D>
-__global__ __launch_bounds__(512, 6) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+__global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                                  int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx)
 {
     __shared__ __attribute__((aligned(16))) unsigned colbuf[K16_COLS * K16_LDC + 8];
-    __shared__ __attribute__((aligned(16))) unsigned hist_all[8 * K16_HIST_WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned hist_all[K16_COL_WAVES * K16_HIST_WORDS];
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
     const int p = lb / col_blocks;
     const int j0 = (lb % col_blocks) * K16_COLS;
@@ -155,7 +158,7 @@ __global__ __launch_bounds__(512, 6) void select_cols_k16_kernel(const uint16_t 
     {
         // thread (c2, rp): columns 4 c2 .. 4 c2 + 3 of the row pair 64 s + rp (rows 128 s + 2 rp, + 1) for s = 0..7; that pair
         // belongs to lane 8 s + (rp >> 3) of the selecting waves, as its word u = rp & 7
-        const int c2 = threadIdx.x & 7, rp = threadIdx.x >> 3;
+        const int c2 = threadIdx.x & (K16_COL_WAVES - 1), rp = threadIdx.x / K16_COL_WAVES;
         const bool fast = ((ds.crp_pitch & 3) == 0) && ((ds.crp_off & 3) == 0) && (j0 + K16_COLS <= N);      // block-uniform: 8-byte loads
         uint2 ta[8], tb[8];
         if (fast) {
@@ -373,8 +376,8 @@ extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float 
     }
     if (mutual == 2) return ACOSS_OK;           // measurement: the row selection kernel alone (bench.py's roofline_selection)
     if (mutual) {
-        if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
-        else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(512), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
+        if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
+        else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
         rc = launch_check("select_cols_k16_kernel");
         if (rc) return rc;
         if (mutual == 3) return ACOSS_OK;
