@@ -746,16 +746,26 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc
     const int W = w.wpr, ld = W + 1;
     const int rows = min(64, M - ri * 64);
     const int64_t base = ((int64_t)p * w.max_m + ri * 64) * W;          // the block's rows are contiguous: rows * W words
-    for (int idx = threadIdx.x; idx < rows * W; idx += 256) rowbuf[(idx / W) * ld + idx % W] = w.row_bits[base + idx];
-    __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    // the column words of this wave's tiles are requested together with the rows (one round trip instead of two)
+    constexpr int TPW = COMBINE_MAXW / 4;
+    uint64_t cwd[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+        const int j = (wave + 4 * t) * 64 + lane;
+        cwd[t] = (mutual && j < N && wave + 4 * t < W) ? *w.col_word(p, j, ri) : 0ull;
+    }
+    for (int idx = threadIdx.x; idx < rows * W; idx += 256) rowbuf[(idx / W) * ld + idx % W] = w.row_bits[base + idx];
+    __syncthreads();
     if (mutual) {
-        for (int cw = wave; cw * 64 < N; cw += 4) {
-            const int j = cw * 64 + lane;
-            const uint64_t cwd = j < N ? *w.col_word(p, j, ri) : 0ull;
-            const uint64_t tr = wave_transpose64(cwd, lane);
-            if (lane < rows) rowbuf[lane * ld + cw] &= tr;
+#pragma unroll
+        for (int t = 0; t < TPW; t++) {
+            const int cw = wave + 4 * t;
+            if (cw * 64 < N) {
+                const uint64_t tr = wave_transpose64(cwd[t], lane);
+                if (lane < rows) rowbuf[lane * ld + cw] &= tr;
+            }
         }
     }
     __syncthreads();

@@ -649,6 +649,103 @@ __global__ __launch_bounds__(256, CPL == 16 ? 4 : 2) void dp_bits_kernel(const u
     if (lane == 0) scores[p] = best;
 }
 
+// ---------------------------------------------------------------------------------------------
+// qmax in 16-bit integers (round 3).  With gamma = 0.5 for onset and extension (gammaState's values, SequenceAlignment.c:104)
+// every D value is a multiple of 0.5 below min(M, N) <= 1024, so E = 2 D is an integer below 2048 and the recurrence
+// (SequenceAlignment.c:113-143) reads: match E = max3 + 2, mismatch E = max(max3 - 1, 0) -- a saturating subtraction.  Two
+// cells per register, on the packed 16-bit instructions: per register and row two v_pk_max_u16, one v_pk_add_u16 of 3 or 0
+// (the two cells' match bits, four registers at a time from a 256-entry table in LDS indexed by a byte of the row's mask bits)
+// and one v_pk_sub_u16 clamp of 1 -- match: + 3 - 1, mismatch: -sat 1 --, the running maximum, and one v_alignbit that forms
+// the row shifted by one cell (used as the diagonal predecessor of the next row and as the (i-2, j-1) predecessor of the one
+// after).  ~59 vector instructions per row against 112 in float32; scores identical by construction (integers; best / 2 is exact).  Same data layout and
+// row pipeline as dp_bits_kernel<KIND_QMAX, 16>.
+// ---------------------------------------------------------------------------------------------
+typedef unsigned short dp_u16x2 __attribute__((ext_vector_type(2)));
+
+__global__ __launch_bounds__(256, 6) void dp_bits_q16_kernel(const uint64_t *__restrict__ bits,
+                                                              const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                              int max_m, float *__restrict__ scores)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lut[256];
+    {
+        // entry b: register r (cells 2r, 2r+1 of a byte's eight) -> 3 in the half of every set bit
+        const unsigned b = threadIdx.x;
+        unsigned e[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[r] = (((b >> (2 * r)) & 1u) ? 3u : 0u) | (((b >> (2 * r + 1)) & 1u) ? 0x30000u : 0u);
+        lut[b] = make_uint4(e[0], e[1], e[2], e[3]);
+    }
+    __syncthreads();
+    constexpr int PF = 12;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (M < 3 || N < 3) {                        // SequenceAlignment.c:117-119
+        if (lane == 0) scores[p] = 0.0f;
+        return;
+    }
+    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    unsigned d1[8], d1s[8], d2s[8];              // row i-1; row i-1 and row i-2 shifted right by one cell
+#pragma unroll
+    for (int k = 0; k < 8; k++) d1[k] = d1s[k] = d2s[k] = 0u;
+    unsigned best = 0u;
+    const bool l0 = lane == 0;
+    const dp_u16x2 one = (dp_u16x2){1, 1};
+    auto pk = [](unsigned v) { return __builtin_bit_cast(dp_u16x2, v); };
+    auto un = [](dp_u16x2 v) { return __builtin_bit_cast(unsigned, v); };
+    // (the masks of a row are requested from the table one row ahead)
+    auto do_row = [&](const uint4 ma, const uint4 mb) {
+        const unsigned mask[8] = {ma.x, ma.y, ma.z, ma.w, mb.x, mb.y, mb.z, mb.w};
+        const unsigned halo = (unsigned)lane_shr1((int)d1[7], 0);       // cells -2, -1: the previous lane's last register
+        unsigned nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned left2 = k >= 1 ? d1[k - 1] : halo;
+            const dp_u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(pk(d1s[k]), pk(d2s[k])), pk(left2));
+            unsigned v = un(__builtin_elementwise_sub_sat(m + pk(mask[k]), one));        // match: + 3 - 1; mismatch: -sat 1
+            if (k == 0) v = l0 ? 0u : v;         // columns 0 and 1 are never written (SequenceAlignment.c:121)
+            best = un(__builtin_elementwise_max(pk(best), pk(v)));
+            nd[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) d2s[k] = d1s[k];
+#pragma unroll
+        for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        d1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d1[k] = nd[k];
+    };
+    // (bits past column N are zero by construction; rows 0 and 1 are never written)
+    int i = 2;
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+    uint4 na = lut[ring[0] & 0xFFu], nb = lut[(ring[0] >> 8) & 0xFFu];
+    for (; i + PF <= M; i += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const uint4 ma = na, mb = nb;
+            ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
+            const unsigned mn = ring[(u + 1) % PF];          // row i + u + 1 (u = PF - 1: the row requested at u = 0 of this trip)
+            na = lut[mn & 0xFFu];
+            nb = lut[(mn >> 8) & 0xFFu];
+            do_row(ma, mb);
+        }
+    }
+#pragma unroll 1
+    for (; i < M; i++) {
+        const unsigned m0 = rowp[(int64_t)i * 64];
+        do_row(lut[m0 & 0xFFu], lut[(m0 >> 8) & 0xFFu]);
+    }
+    unsigned b = max(best & 0xFFFFu, best >> 16);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+    if (lane == 0) scores[p] = 0.5f * (float)b;
+}
+
 // qmax and dmax of the same mask in ONE sweep (what Serra09.similarity asks for, Serra09.py:173-175: dmax on the D
 // that qmax leaves behind = `boundary`): the two recurrences are independent given the mask rows, so their
 // dependent chains interleave in one instruction stream and the mask is read once.  Same arithmetic per kind as
@@ -844,7 +941,10 @@ int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc
     const float4 sw = make_float4(ap.sw_match, ap.sw_mismatch, ap.sw_gap_open, ap.sw_gap_ext);
     const dim3 grid(ceil_div(K, 4));
     if (mask_bits_words(max_m, max_n) == 16) {
-        if (kind == 0)
+        static const bool q16 = []() { const char *e = getenv("ACOSS_DP_Q16"); return !(e && e[0] == '0'); }();
+        if (kind == 0 && q16 && ap.gamma_onset == 0.5f)        // (checked above: gamma_extension equals it)
+            hipLaunchKernelGGL(dp_bits_q16_kernel, grid, dim3(256), 0, st, bits, descs, K, win, max_m, scores);
+        else if (kind == 0)
             hipLaunchKernelGGL((dp_bits_kernel<KIND_QMAX, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
         else if (kind == 1)
             hipLaunchKernelGGL((dp_bits_kernel<KIND_DMAX, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, boundary, sw, scores);
