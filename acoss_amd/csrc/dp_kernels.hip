@@ -746,6 +746,123 @@ __global__ __launch_bounds__(256, 6) void dp_bits_q16_kernel(const uint64_t *__r
     if (lane == 0) scores[p] = 0.5f * (float)b;
 }
 
+// dmax in 16-bit integers: the same construction for SequenceAlignment.c:147-180 (E = 2 D <= 6 * 1024: every step adds at most
+// 1 + two mask values).  Five predecessors, four of them with mask values of the skipped cells added (2 per set bit in E
+// units): (i-2, j-1) + S[i-1][j]; (i-1, j-2) + S[i][j-1]; (i-3, j-1) + S[i-2][j] + S[i-1][j]; (i-1, j-3) + S[i][j-2] + S[i][j-1].
+// Rows shifted by one cell are kept for i-1, i-2, i-3 (one v_alignbit per register and row forms the new one), shifts by two
+// and three are the neighbouring registers of the plain and the shifted row.  boundary = 1: D as qmax leaves it (Serra09.py:
+// 173-175): row 2 and column 2 hold the mask values.
+__global__ __launch_bounds__(256, 4) void dp_bits_d16_kernel(const uint64_t *__restrict__ bits,
+                                                              const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                              int max_m, int boundary, float *__restrict__ scores)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lut[256];
+    {
+        const unsigned b = threadIdx.x;
+        unsigned e[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[r] = (((b >> (2 * r)) & 1u) ? 3u : 0u) | (((b >> (2 * r + 1)) & 1u) ? 0x30000u : 0u);
+        lut[b] = make_uint4(e[0], e[1], e[2], e[3]);
+    }
+    __syncthreads();
+    constexpr int PF = 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (M < 4 || N < 4) {                        // SequenceAlignment.c:151-153
+        if (lane == 0) scores[p] = 0.0f;
+        return;
+    }
+    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    auto pk = [](unsigned v) { return __builtin_bit_cast(dp_u16x2, v); };
+    auto un = [](dp_u16x2 v) { return __builtin_bit_cast(unsigned, v); };
+    const dp_u16x2 one = (dp_u16x2){1, 1};
+    const bool l0 = lane == 0;
+    // the mask values (2 per set bit) of a row's cells, per register
+    auto row_vals = [&](const unsigned m0, unsigned (&m3)[8], unsigned (&a)[8]) {
+        const uint4 ma = lut[m0 & 0xFFu], mb = lut[(m0 >> 8) & 0xFFu];
+        m3[0] = ma.x; m3[1] = ma.y; m3[2] = ma.z; m3[3] = ma.w; m3[4] = mb.x; m3[5] = mb.y; m3[6] = mb.z; m3[7] = mb.w;
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] = m3[k] & 0x00020002u;
+    };
+    unsigned d1[8], d1s[8], d2s[8], d3s[8];      // row i-1; rows i-1, i-2, i-3 shifted right by one cell
+    unsigned a1[8], a2[8];                       // mask values of rows i-1, i-2
+#pragma unroll
+    for (int k = 0; k < 8; k++) d1[k] = d1s[k] = d2s[k] = d3s[k] = a1[k] = a2[k] = 0u;
+    // rows 1 and 2 only leave their mask values behind; with the boundary row 2 of D holds them too (columns >= 2)
+    {
+        unsigned m3[8];
+        row_vals((unsigned)rowp[(int64_t)1 * 64], m3, a2);
+        row_vals((unsigned)rowp[(int64_t)2 * 64], m3, a1);
+        if (boundary) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) d1[k] = a1[k];
+            if (l0) d1[0] = 0u;
+#pragma unroll
+            for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(d1[k], d1[k - 1], 16);
+            d1s[0] = __builtin_amdgcn_alignbit(d1[0], (unsigned)lane_shr1((int)d1[7], 0), 16);
+        }
+    }
+    unsigned best = 0u;
+    auto do_row = [&](const unsigned m0) {
+        unsigned m3[8], a0[8];
+        row_vals(m0, m3, a0);
+        const unsigned a0_prev = (unsigned)lane_shr1((int)a0[7], 0);     // cells -2, -1 of this row's mask values
+        const unsigned d1_prev = (unsigned)lane_shr1((int)d1[7], 0);
+        const unsigned d1s_prev = (unsigned)lane_shr1((int)d1s[7], 0);
+        unsigned nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned a0m1 = k >= 1 ? a0[k - 1] : a0_prev;                    // S[i][j-2] (x 2)
+            const dp_u16x2 sl1 = pk(__builtin_amdgcn_alignbit(a0[k], a0m1, 16));   // S[i][j-1]
+            const dp_u16x2 su1 = pk(a1[k]), su2 = pk(a2[k]);                        // S[i-1][j], S[i-2][j]
+            const dp_u16x2 c1 = pk(d1s[k]);                                          // (i-1, j-1)
+            const dp_u16x2 c2 = pk(d2s[k]) + su1;                                    // (i-2, j-1)
+            const dp_u16x2 c3 = pk(k >= 1 ? d1[k - 1] : d1_prev) + sl1;              // (i-1, j-2)
+            const dp_u16x2 c4 = pk(d3s[k]) + (su2 + su1);                            // (i-3, j-1)
+            const dp_u16x2 c5 = pk(k >= 1 ? d1s[k - 1] : d1s_prev) + (pk(a0m1) + sl1);      // (i-1, j-3)
+            const dp_u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(c1, c2), __builtin_elementwise_max(c3, c4)), c5);
+            unsigned v = un(__builtin_elementwise_sub_sat(m + pk(m3[k]), one));
+            unsigned vb = v;                     // what counts for the maximum: columns >= 3
+            if (k == 0) { v = l0 ? 0u : v; vb = v; }
+            if (k == 1) {
+                vb = l0 ? (v & 0xFFFF0000u) : v;
+                v = l0 ? ((v & 0xFFFF0000u) | (boundary ? (a0[1] & 0xFFFFu) : 0u)) : v;       // column 2 = S[i][2] with the boundary
+            }
+            best = un(__builtin_elementwise_max(pk(best), pk(vb)));
+            nd[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { d3s[k] = d2s[k]; d2s[k] = d1s[k]; a2[k] = a1[k]; a1[k] = a0[k]; }
+#pragma unroll
+        for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        d1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d1[k] = nd[k];
+    };
+    int i = 3;
+    unsigned ring[PF];
+#pragma unroll
+    for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+    for (; i + PF <= M; i += PF) {
+#pragma unroll
+        for (int u = 0; u < PF; u++) {
+            const unsigned m0 = ring[u];
+            ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
+            do_row(m0);
+        }
+    }
+#pragma unroll 1
+    for (; i < M; i++) do_row((unsigned)rowp[(int64_t)i * 64]);
+    unsigned b = max(best & 0xFFFFu, best >> 16);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
+    if (lane == 0) scores[p] = 0.5f * (float)b;
+}
+
 // qmax and dmax of the same mask in ONE sweep (what Serra09.similarity asks for, Serra09.py:173-175: dmax on the D
 // that qmax leaves behind = `boundary`): the two recurrences are independent given the mask rows, so their
 // dependent chains interleave in one instruction stream and the mask is read once.  Same arithmetic per kind as
@@ -944,6 +1061,8 @@ int acoss_align_bits_batch(int kind, const uint64_t *bits, const acoss_pair_desc
         static const bool q16 = []() { const char *e = getenv("ACOSS_DP_Q16"); return !(e && e[0] == '0'); }();
         if (kind == 0 && q16 && ap.gamma_onset == 0.5f)        // (checked above: gamma_extension equals it)
             hipLaunchKernelGGL(dp_bits_q16_kernel, grid, dim3(256), 0, st, bits, descs, K, win, max_m, scores);
+        else if (kind == 1 && q16 && ap.gamma_onset == 0.5f)
+            hipLaunchKernelGGL(dp_bits_d16_kernel, grid, dim3(256), 0, st, bits, descs, K, win, max_m, boundary, scores);
         else if (kind == 0)
             hipLaunchKernelGGL((dp_bits_kernel<KIND_QMAX, 16>), grid, dim3(256), 0, st, bits, descs, K, win, max_m, ap.gamma_onset, 0, sw, scores);
         else if (kind == 1)
