@@ -249,7 +249,10 @@ int acoss_align_fused_batch(int kind, const double *T, const acoss_pair_desc *de
  * column's selected positions as bit vectors by ballot; a tile kernel transposes the column vectors and ANDs.
  * `work` needs acoss_mask_bits_work_bytes() bytes (thresholds + the two bit planes).
  * acoss_align_bits_batch runs qmax (kind 0) / dmax (kind 1) / swalignimpconstrained (kind 2) from those bits, one wave per pair
- * (gamma_onset == gamma_extension required; `boundary` as for acoss_dmax_batch). */
+ * (gamma_onset == gamma_extension required; `boundary` as for acoss_dmax_batch).  With gamma = 0.5 (gammaState's value,
+ * SequenceAlignment.c:104) and matrices up to 1024 x 1024, qmax and dmax run in 16-bit integers on E = 2 D (every D is a
+ * multiple of 0.5; the reference's float32 arithmetic is exact on them): the same scores, about half the instructions.
+ * Environment ACOSS_DP_Q16=0 (read once per process) keeps the float32 kernels. */
 int acoss_mask_bits_words(int max_nx, int max_ny, int win);
 size_t acoss_mask_bits_work_bytes(int K, int max_nx, int max_ny, int win);
 int acoss_mask_bits_batch(const double *S, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
