@@ -755,19 +755,7 @@ __global__ __launch_bounds__(64) void band_fix_kernel(const double *__restrict__
 // Bit-packed mutual mask from the planes of the band kernel: out[p][i][cw] (uint64, bit c = column cw*64 + c) = the
 // row plane of row i AND the transposed column planes, both with their plane shift taken out.  One block per 64 rows of
 // a pair (cf. combine_bits_kernel, crp_kernels.hip: same staging and the same 64 x 64 butterfly transpose).
-__device__ inline uint64_t bd_transpose64(uint64_t x, int lane)
-{
-#pragma unroll
-    for (int j = 32; j >= 1; j >>= 1) {
-        const uint64_t m = j == 32 ? 0x00000000ffffffffull : j == 16 ? 0x0000ffff0000ffffull : j == 8 ? 0x00ff00ff00ff00ffull
-                         : j == 4 ? 0x0f0f0f0f0f0f0f0full : j == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-        const unsigned ylo = (unsigned)__shfl_xor((int)(unsigned)x, j);
-        const unsigned yhi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), j);
-        const uint64_t y = ((uint64_t)yhi << 32) | ylo;
-        x = (lane & j) ? ((x & ~m) | ((y & ~m) >> j)) : ((x & m) | ((y & m) << j));
-    }
-    return x;
-}
+__device__ inline uint64_t bd_transpose64(uint64_t x, int lane) { return wave_transpose64(x, lane); }      // wave_ops.h
 
 __global__ __launch_bounds__(256) void combine_planes_kernel(const acoss_pair_desc *__restrict__ descs, int win, int mutual,
                                                              BandWork bw, int tiles_m, uint64_t *__restrict__ out)

@@ -709,24 +709,6 @@ __device__ inline uint64_t spread_bits32(unsigned a)
     return x;
 }
 
-// 64 x 64 bit transpose across a wave: lane r holds row r (bit c = column c) -> lane c holds column c (bit r = row r).
-// Six butterfly steps (block sizes 32 .. 1): lanes r and r ^ j exchange the off-diagonal j x j blocks of every 2j x 2j
-// block; ~70 instructions instead of 64 ballots.
-__device__ inline uint64_t wave_transpose64(uint64_t x, int lane)
-{
-#pragma unroll
-    for (int j = 32; j >= 1; j >>= 1) {
-        // columns c with (c & j) == 0
-        const uint64_t m = j == 32 ? 0x00000000ffffffffull : j == 16 ? 0x0000ffff0000ffffull : j == 8 ? 0x00ff00ff00ff00ffull
-                         : j == 4 ? 0x0f0f0f0f0f0f0f0full : j == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
-        const unsigned ylo = (unsigned)__shfl_xor((int)(unsigned)x, j);
-        const unsigned yhi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), j);
-        const uint64_t y = ((uint64_t)yhi << 32) | ylo;
-        x = (lane & j) ? ((x & ~m) | ((y & ~m) >> j)) : ((x & m) | ((y & m) << j));
-    }
-    return x;
-}
-
 // Bit-packed mutual mask: out[p][i][cw] (uint64, bit c = column cw*64 + c) = row_bits[i][cw] & the transpose
 // of col_bits.  One block per 64 rows of a pair: the rows' words come in and go out through LDS with fully
 // coalesced accesses (64 rows x W words are contiguous in both arrays); wave v takes the 64 x 64 tiles cw = v, v+4, ...:

@@ -463,4 +463,31 @@ __device__ inline SelectResult wave_select16_hist(const double (&x)[16], IdxFn i
     return res;
 }
 
+// 64 x 64 bit transpose across a wave: lane r holds row r (bit c = column c) -> lane c holds column c (bit r = row r).
+// Six butterfly steps (block sizes 32 .. 1): lanes r and r ^ j exchange the off-diagonal j x j blocks of every 2j x 2j
+// block; ~70 instructions instead of 64 ballots.  (One template instance per step: written as a loop over j, hipcc left it
+// a run-time loop with a switch for the masks wherever the function was inlined more than once.)
+template <int J>
+__device__ inline uint64_t wave_transpose64_step(uint64_t x, int lane)
+{
+    // columns c with (c & J) == 0
+    constexpr uint64_t m = J == 32 ? 0x00000000ffffffffull : J == 16 ? 0x0000ffff0000ffffull : J == 8 ? 0x00ff00ff00ff00ffull
+                         : J == 4 ? 0x0f0f0f0f0f0f0f0full : J == 2 ? 0x3333333333333333ull : 0x5555555555555555ull;
+    const unsigned ylo = (unsigned)__shfl_xor((int)(unsigned)x, J);
+    const unsigned yhi = (unsigned)__shfl_xor((int)(unsigned)(x >> 32), J);
+    const uint64_t y = ((uint64_t)yhi << 32) | ylo;
+    return (lane & J) ? ((x & ~m) | ((y & ~m) >> J)) : ((x & m) | ((y & m) << J));
+}
+
+__device__ inline uint64_t wave_transpose64(uint64_t x, int lane)
+{
+    x = wave_transpose64_step<32>(x, lane);
+    x = wave_transpose64_step<16>(x, lane);
+    x = wave_transpose64_step<8>(x, lane);
+    x = wave_transpose64_step<4>(x, lane);
+    x = wave_transpose64_step<2>(x, lane);
+    x = wave_transpose64_step<1>(x, lane);
+    return x;
+}
+
 }  // namespace acoss
