@@ -287,8 +287,8 @@ int acoss_ftm2d_shingles(const double *btchroma, const int64_t *beat_off_host, i
         hipLaunchKernelGGL(ftm2d_normalize_kernel, dim3((unsigned)n_songs), dim3(256), 0, st, d_med, d_tables + (n_songs + 1), shingles);
         rc = launch_check("ftm2d_normalize_kernel");
     }
-    hipStreamSynchronize(st);      // the offset tables (host and device copies) must outlive the kernels
-    hipFree(d_tables);
+    (void)hipStreamSynchronize(st);      // the offset tables (host and device copies) must outlive the kernels
+    (void)hipFree(d_tables);
     free(offs);
     return rc;
 }

@@ -336,7 +336,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                 for (int k = 0; k < n_feat; k++)
                     if (k != i) list[n++] = (it == 0) ? Pm[k] : Pm[k];
                 if (hipMemcpyAsync((void *)d_ptrs, list, sizeof(double *) * (size_t)n, hipMemcpyHostToDevice, st) != hipSuccess) { rc = ACOSS_EIO; break; }
-                hipStreamSynchronize(st);       // `list` is a stack array
+                (void)hipStreamSynchronize(st);       // `list` is a stack array
                 hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n, tot, Xm);
                 src = Xm;
             }
@@ -354,7 +354,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
         const double *list[8];
         for (int f = 0; f < n_feat; f++) list[f] = Pm[f];
         if (hipMemcpyAsync((void *)d_ptrs, list, sizeof(double *) * (size_t)n_feat, hipMemcpyHostToDevice, st) != hipSuccess) rc = ACOSS_EIO;
-        hipStreamSynchronize(st);
+        (void)hipStreamSynchronize(st);
         if (rc == ACOSS_OK) {
             int maxM = 0, maxN = 0;
             for (int p = 0; p < K; p++) { maxM = M[p] > maxM ? M[p] : maxM; maxN = N[p] > maxN ? N[p] : maxN; }
@@ -367,7 +367,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
             }
         }
     }
-    hipStreamSynchronize(st);       // the host table must outlive its upload
+    (void)hipStreamSynchronize(st);       // the host table must outlive its upload
     free(tab);
     return rc;
 }

@@ -29,9 +29,8 @@ typedef float v2f32 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2s_t __attribute__((ext_vector_type(2)));
 
 constexpr int S32_ROWS = 32;            // C rows per step
-constexpr int S32_CT = 128;             // C columns per strip
 constexpr int S32_WIN = 9, S32_HALO = S32_WIN - 1;
-constexpr int S32_TN = 112;             // output columns per strip (<= S32_CT - S32_HALO): 448-byte row pieces, every one
+constexpr int S32_TN = 112;             // output columns per strip (<= 128 C columns - S32_HALO): 448-byte row pieces, every one
                                         // 64-byte aligned when the pitch is; 120-column pieces (half of them 32 bytes off) store 27 % slower
 constexpr int S32_LD = 131;             // odd: the two-element diagonal reads (row stride LD + 1) stay 8-byte aligned
 constexpr int S32_XLD = 17;             // packed x line: 16 floats

@@ -382,7 +382,7 @@ __device__ inline SelectResult wave_select16_hist(const double (&x)[16], IdxFn i
         } else {
 #pragma unroll
             for (int e = 0; e < 16; e++)
-                below += __popcll(__ballot((key_hi(x[e]) < lo) & (idx_of(e) < n)));
+                below += __popcll(__ballot((int)(key_hi(x[e]) < lo) & (int)(idx_of(e) < n)));
         }
         const unsigned spill = (unsigned)(HIST_BINS + lane);
 #pragma unroll
