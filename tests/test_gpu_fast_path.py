@@ -512,3 +512,53 @@ def test_float32_filter_is_scale_free(eng, orc):
             q, d = orc.serra09_pair(feats[ch.frame_off[i]:ch.frame_off[i + 1]], ch.gchroma[i],
                                     feats[ch.frame_off[j]:ch.frame_off[j + 1]], ch.gchroma[j])
             assert got["qmax"][t] == q and got["dmax"][t] == d, (mag, t)
+
+
+def test_float32_error_bound_under_adversarial_features(eng, orc):
+    """The float32 filter's certificate, |T~ - T| <= 2^-24 (16.5 W + 9.5 T), on features built to stress it -- near-duplicate
+    frames of large norm (every distance is a cancellation), two far-apart clusters (after centring: norms huge against the
+    within-cluster distances), one dominant bin, heavy-tailed magnitudes, alternating signs (13-d MFCC-like) -- and, with the
+    bound holding, the scores of the whole chain against the oracle.  Reports how much of the bound the worst cell uses."""
+    rng = np.random.default_rng(2026)
+    n = 230
+
+    def chroma_like(x):
+        return np.abs(x) + 1e-3
+
+    base = rng.lognormal(0.0, 2.0, (n, 12))
+    fams = {
+        "near_duplicates": [chroma_like(base * (1.0 + 1e-4 * rng.standard_normal((n, 12)))) for _ in range(3)],
+        "two_clusters": [chroma_like(np.where((np.arange(n) % 2 == s)[:, None], 100.0, 1.0) * (1.0 + 1e-3 * rng.random((n, 12)))) for s in range(3)],
+        "dominant_bin": [chroma_like(np.concatenate([1e3 * (1 + 1e-5 * rng.random((n, 1))), 1e-2 * rng.random((n, 11))], axis=1)) for _ in range(3)],
+        "heavy_tail": [chroma_like(rng.lognormal(0.0, 3.0, (n, 12))) for _ in range(3)],
+    }
+    worst = {}
+    for name, songs in fams.items():
+        feats = np.concatenate(songs)
+        off = np.arange(len(songs) + 1, dtype=np.int64) * n
+        gc = np.stack([s.sum(0) / s.sum(0).max() for s in songs])
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        pairs = np.array([(0, 1), (1, 2), (2, 0), (1, 1)], dtype=np.int32)
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+        eng.oti(corpus, batch)
+        if not eng.keys16_supported(corpus, batch):
+            continue                                   # (the engine itself refuses the filter for this corpus: float64 path)
+        T = eng.crp(corpus, batch, eng.pack_x(corpus, batch)).cpu().numpy()
+        Kh = eng.crp_planar32(corpus, batch, eng.pack_x32(corpus, batch)).cpu().numpy().view(np.uint32)
+        bh = eng.planar32_band(corpus, batch).cpu().numpy().astype(np.float64)
+        ratio = 0.0
+        for p in range(batch.K):
+            d = batch.descs[p]
+            M, N = int(d["nx"]) - 8, int(d["ny"]) - 8
+            idx = (int(d["crp_off"]) + np.arange(M)[:, None] * int(d["crp_pitch"]) + np.arange(N)[None, :]).astype(np.int64)
+            approx = (Kh[idx] & 0x7fffffff).astype(np.uint32).view(np.float32).astype(np.float64)
+            Ts = T[idx] * corpus._f32_scale2
+            bound = (bh[2 * p] + bh[2 * p + 1] * Ts) / 2
+            ratio = max(ratio, float(np.max(np.abs(approx - Ts) / bound)))
+        worst[name] = ratio
+        assert ratio <= 1.0, (name, ratio)
+        got = eng.serra09_scores(corpus, pairs)
+        q, dm, _ = orc.serra09_pairs(feats, off, gc, pairs, nthreads=4)
+        assert np.array_equal(got["qmax"], q) and np.array_equal(got["dmax"], dm), name
+    print("worst |T~ - T| / bound per family:", {k: round(v, 3) for k, v in worst.items()})
+    assert len(worst) >= 3
