@@ -47,7 +47,7 @@ __device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, i
 // K16_ROWS_PER_WAVE rows per wave): equal wave loads for every song length, and long runs of rows inside one predicted window.
 constexpr int K16_ROWS_PER_WAVE = 32;
 #ifndef K16_ROWS_WPS
-#define K16_ROWS_WPS 8
+#define K16_ROWS_WPS 7                     // 72 registers: no spills, and the kernel keeps 7.1 of 8 waves resident anyway
 #endif
 
 // ---- rows ------------------------------------------------------------------------------------------------------------------
