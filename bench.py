@@ -356,6 +356,13 @@ def attach_profile_averages(out, P, args):
             if prefix in name:
                 return ms
         return None
+    pmc = {}
+    pmc_f = os.path.join(ROOT, "profiles", "r03_pmc.json")
+    if os.path.exists(pmc_f):
+        with open(pmc_f) as fh:
+            pmc = json.load(fh)
+        if pmc.get("_path") != args.path or pmc.get("_pairs_per_step") != P:
+            pmc = {}
     blocks = [out.get("roofline")]
     if "roofline_selection" in out:
         blocks += [out["roofline_selection"].get("rows"), out["roofline_selection"].get("cols")]
@@ -372,6 +379,15 @@ def attach_profile_averages(out, P, args):
         blk["profiles_avg_launch_ms"] = round(ms, 4)
         blk["profiles_frac"] = round(work / ms / 1e6 / blk["peak"], 4) if blk["unit"] == "GB/s" else None
         blk["profiles_source"] = "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `%s`)" % meta.get("command", "bench.py")
+        # what the kernel is bound by when it is not HBM: the SIMDs' busy fractions from the committed counter passes (SQ counters
+        # in quad-cycles, MI355X_MICROARCH.md; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)
+        c = pmc.get(key)
+        if c and c.get("GRBM_GUI_ACTIVE") and c.get("SQ_ACTIVE_INST_VALU") is not None:
+            cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+            blk["simd_busy"] = {"valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 3),
+                                "mfma": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc, 3),
+                                "waves_per_simd_resident": round(c["SQ_WAVE_CYCLES"] * 4.0 / 1024.0 / cyc, 2),
+                                "source": "profiles/r03_pmc.json (rocprofv3 --pmc passes of the same command; fractions of the kernel's cycles on the 1024 SIMDs)"}
 
 
 def extras_config3(engine, synth, oracle, threads, torch):
