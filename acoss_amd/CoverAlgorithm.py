@@ -182,15 +182,18 @@ class CoverAlgorithm(object):
             self.get_all_clique_ids()
         else:
             all_pairs = self._pair_list(symmetric)
-            rank, world, dist = 0, 1, None
+            rank, world, dist, sharded = 0, 1, None, False
             try:
                 import torch.distributed as dist
                 if dist.is_available() and dist.is_initialized():
                     rank, world = dist.get_rank(), dist.get_world_size()
+                    # ACOSS_FORCE_COLLECTIVE=1: shard and gather even in a one-rank group (how a one-GPU box runs the
+                    # RCCL all-gather of this driver: tests/test_gpu_rccl.py)
+                    sharded = world > 1 or os.environ.get("ACOSS_FORCE_COLLECTIVE", "0") == "1"
             except ImportError:
                 dist = None
             mine = np.arange(len(all_pairs))
-            if world > 1:
+            if sharded:
                 from . import sharding
                 costs = self._pair_costs(all_pairs)
                 mine = sharding.shard_indices(costs, world, rank)
@@ -207,12 +210,16 @@ class CoverAlgorithm(object):
                 self.Ds = {s: np.zeros((self.N, self.N), dtype=np.float32) for s in self.similarity_types}
             for s in self.similarity_types:
                 full = local[s]
-                if world > 1:
+                if sharded:
                     import torch
                     from . import sharding
                     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
                     full = sharding.gather_scores(torch.from_numpy(local[s]).to(dev), mine, len(all_pairs),
-                                                  index_of_rank=lambda r: sharding.shard_indices(costs, world, r)).cpu().numpy()
+                                                  index_of_rank=lambda r: sharding.shard_indices(costs, world, r),
+                                                  force_collective=True).cpu().numpy()
+                # a matrix kept from an earlier call starts from zero again: `Ds += Ds.T` below would otherwise add the new
+                # upper triangle to the old lower one (the reference's matrices are fresh 'w+' memmaps, CoverAlgorithm.py:52-55)
+                self.Ds[s][:] = 0
                 self.Ds[s][all_pairs[:, 0], all_pairs[:, 1]] = full
             self.get_all_clique_ids()
             if symmetric:

@@ -53,7 +53,17 @@ class Serra09(CoverAlgorithm):
     KEYS = ["ssms_scatter_qmax", "ssms_scatter_dmax", "chroma_qmax", "chroma_dmax", "mfcc_qmax", "mfcc_dmax"]
 
     def __init__(self, datapath="../features_covers80", chroma_type='crema', shortname='benchmark',
-                 oti=True, kappa=0.095, m=9, downsample_fac=40, do_memmaps=True, cachedir="cache"):
+                 oti=True, kappa=0.095, m=9, downsample_fac=40, do_memmaps=True, cachedir="cache",
+                 alignments=("qmax", "dmax")):
+        """The reference's keywords (Serra09.py:86-94) plus `alignments`: the recurrences run on every mask.  The default is
+        the reference's pair (qmax, then dmax on the same D).  "swc" adds SequenceAlignment.c's constrained Smith-Waterman
+        (BASELINE config 3, "Serra09 Smith-Waterman constrained") on the same mutual mask, called as its one caller in the
+        reference does (EarlySNF_Old.py:198-203: a fresh (M+1) x (N+1) D, rows first) and normalised like the other two:
+        three more keys, `chroma_swc`, `mfcc_swc`, `ssms_scatter_swc` = swconstrained / (M + N)."""
+        bad = [a for a in alignments if a not in ("qmax", "dmax", "swc")]
+        if bad or "qmax" not in alignments or "dmax" not in alignments:
+            raise ValueError("Serra09: alignments must hold 'qmax' and 'dmax' (the reference's keys) and may add 'swc'; got %r" % (alignments,))
+        self.alignments = tuple(a for a in ("qmax", "dmax", "swc") if a in alignments)
         self.oti = oti
         self.m = m
         self.chroma_type = chroma_type
@@ -61,8 +71,11 @@ class Serra09(CoverAlgorithm):
         self.downsample_fac = downsample_fac
         self._dev = {}
         self._warned_ssms = False
+        keys = list(self.KEYS)
+        if "swc" in self.alignments:
+            keys += ["ssms_scatter_swc", "chroma_swc", "mfcc_swc"]
         CoverAlgorithm.__init__(self, "Serra09", datapath=datapath, shortname=shortname, do_memmaps=do_memmaps,
-                                similarity_types=list(self.KEYS), cachedir=cachedir)
+                                similarity_types=keys, cachedir=cachedir)
 
     # ------------------------------------------------------------------------------------------
     def load_features(self, i):
@@ -133,26 +146,27 @@ class Serra09(CoverAlgorithm):
 
     def _chain(self, key, idxs, win, do_oti):
         corpus, where = self._device_corpus(key, np.unique(idxs).astype(np.int64))
-        return engine.serra09_scores(corpus, where[idxs], m=win, kappa=self.kappa, do_oti=do_oti)
+        return engine.serra09_scores(corpus, where[idxs], m=win, kappa=self.kappa, do_oti=do_oti, want=self.alignments)
 
     def similarity(self, idxs):
         idxs = np.asarray(idxs).reshape(-1, 2)
         K = idxs.shape[0]
-        similarities = {key: np.zeros(K) for key in self.KEYS}
+        similarities = {key: np.zeros(K) for key in self.similarity_types}
         if K == 0:
             return similarities
         have = self.load_features(int(idxs[0, 0]))
+
+        def take(prefix, res):
+            for a in self.alignments:
+                similarities["%s_%s" % (prefix, a)] = res[a]
         # Step 1: chroma (OTI)                                   Serra09.py:165-175
-        res = self._chain('chroma', idxs, self.m, self.oti)
-        similarities['chroma_qmax'], similarities['chroma_dmax'] = res['qmax'], res['dmax']
+        take('chroma', self._chain('chroma', idxs, self.m, self.oti))
         # Step 2: MFCC (no OTI)                                  Serra09.py:177-184
         if 'mfcc' in have:
-            res = self._chain('mfcc', idxs, self.m, False)
-            similarities['mfcc_qmax'], similarities['mfcc_dmax'] = res['qmax'], res['dmax']
+            take('mfcc', self._chain('mfcc', idxs, self.m, False))
         # Step 3: SSM-scatter features, no sliding window        Serra09.py:186-192
         if 'ssms' in have:
-            res = self._chain('ssms', idxs, 1, False)
-            similarities['ssms_scatter_qmax'], similarities['ssms_scatter_dmax'] = res['qmax'], res['dmax']
+            take('ssms_scatter', self._chain('ssms', idxs, 1, False))
         elif not self._warned_ssms:
             warnings.warn("no 'ssms' features: ssms_scatter_* scores are left at zero "
                           "(scattering features are outside the accelerated path)")

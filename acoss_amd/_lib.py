@@ -60,6 +60,7 @@ SIGNATURES = {
     "acoss_csm_packed_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_csm_packed_batch_f32": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_csm_strip_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
+    "acoss_csm_rows_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp]),
     "acoss_crp_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "acoss_crp_planar_batch_f64": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acoss_crp_planar32_batch": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

@@ -55,6 +55,20 @@ __device__ inline double csm_sqrt(double c)
     return g;
 }
 __device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
+// The two halves of csm_sqrt(double) for kernels that take many roots at once: one wave-uniform test over all of a lane's
+// values, then the branch-free iteration (c >= 0, not in (0, 2^-900)) -- the same instructions, the same bits.
+__device__ inline bool csm_sqrt_is_tiny(double c) { return c > 0.0 && c < 0x1.0p-900; }
+__device__ inline double csm_sqrt_fast(double c)
+{
+    const double y = __builtin_amdgcn_rsq(fmax(c, 0x1.0p-900));
+    double g = c * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, c), h, g);
+    g = fma(fma(-g, g, c), h, g);
+    return g;
+}
 
 // The float32 window sum T~ of output row i, as every float32 kernel forms it (strip32_kernels.hip; the recomputation in
 // keys16.h): nine non-negative C values of one diagonal, c[k] = C[i + k][j + k], added pairwise (depth 4: the bound

@@ -108,9 +108,22 @@ __device__ inline float k16_c_value(const float *__restrict__ xrow0, const float
 // above it) and step by at least 2^-15 a: there the band, (2 (d + 4.5) W + 19 a) 2^-24 rounded up <= (8 (d + 4.5) + 19) 2^-24 a
 // < 2^-16.7 a for d <= 13, is narrower than a key, so nothing outside [th - 1, th + 1] is in reach: no float arithmetic on the
 // common path.
-__device__ inline void k16_reach(unsigned th, unsigned koff, const float *pair_band, unsigned &h_lo, unsigned &h_hi)
+//
+// That shortcut rests on the caller's arrays agreeing with each other -- band = (2 (d + 4.5) W, 19) 2^-24 and koff = the pattern
+// of the same 2 W 2^-7 -- and acoss_mask_bits_keys16_batch takes them as independent arguments, so it is CHECKED per pair
+// (k16_reach_adjacent_ok, once per wave): the band at the bottom of the fine region -- the value of key K16_FINE, four octaves
+// above koff's -- and its slope must both stay below one key step, 2^-15 of the value; a pair that fails (a wider band, a koff
+// from a smaller W, koff == 0: a pair too quiet for the window to mean anything) takes the general branch for every threshold.
+__device__ inline bool k16_reach_adjacent_ok(unsigned koff, const float *pair_band)
 {
-    if (koff != 0u && th > K16_FINE && th < K16_MAX) {       // (koff == 0: a pair too quiet for the window to mean anything)
+    if (koff == 0u) return false;
+    const float a0 = __uint_as_float(koff + ((K16_FINE + K16_FINE_BIAS) << 9));
+    return pair_band[1] < 0x1p-15f && fmaf(pair_band[1], a0, pair_band[0]) < 0x1p-15f * a0;
+}
+
+__device__ inline void k16_reach(unsigned th, unsigned koff, bool adjacent_ok, const float *pair_band, unsigned &h_lo, unsigned &h_hi)
+{
+    if (adjacent_ok && th > K16_FINE && th < K16_MAX) {
         h_lo = th - 1u;
         h_hi = min(th + 1u, K16_MAX);
         return;
@@ -310,12 +323,13 @@ enum { K16_DECIDED = 0, K16_HANDOVER = 1 };
 // scratch: K16_SCRATCH words of wave-private LDS, its last 64 words zero on entry and on return.
 template <int D, int DIR>
 __device__ inline int k16_decide(const u16x2 (&h)[8], const Sel16 &s, int k, unsigned *scratch, int lane, const K16Ctx &cx,
-                                 const float *pair_band, unsigned koff, const acoss_pair_desc &ds, int p, int which, unsigned &sel)
+                                 const float *pair_band, unsigned koff, bool adjacent_ok, const acoss_pair_desc &ds, int p, int which,
+                                 unsigned &sel)
 {
     sel = 0;
     if (s.th == 0u || s.th >= K16_MAX) return K16_HANDOVER;              // the threshold left the key range
     unsigned h_lo, h_hi;
-    k16_reach(s.th, koff, pair_band, h_lo, h_hi);
+    k16_reach(s.th, koff, adjacent_ok, pair_band, h_lo, h_hi);
     const bool mine = (s.any >> lane) & 1;
     bool alone;
     if (h_lo >= s.binlo && h_hi <= s.binlo + s.binw)                     // the reach lies inside the last bin: its few keys only

@@ -73,6 +73,7 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
     HistWarm warm{0, K16_SHIFT0};
     const unsigned koff = cx.koff[p];
     const float *pair_band = w.band + 2 * p;
+    const bool adjacent_ok = k16_reach_adjacent_ok(koff, pair_band);
     // lane l reads bytes [32 l, 32 l + 32) of the row; lanes past the end read a block of padding keys instead
     const int n_lanes = (N + 15) >> 4;
     const bool tail = (N & 15) != 0;            // wave-uniform
@@ -101,7 +102,7 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
             sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
         } else {
             const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
-            state = s.ok ? k16_decide<D, 0>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, ds, p, i, sel) : K16_HANDOVER;
+            state = s.ok ? k16_decide<D, 0>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, i, sel) : K16_HANDOVER;
             if (state == K16_HANDOVER) {
                 if (!k16_hand_over(h, w, p, 0, i, s.ok ? s.th : 0u, lane)) {
                     // no room in the side buffer: marked for the strided refinement kernel
@@ -224,6 +225,7 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
     if (warm.hi >= K16_MAX) warm.hi = 0u;
     const unsigned koff = cx.koff[p];
     const float *pair_band = w.band + 2 * p;
+    const bool adjacent_ok = k16_reach_adjacent_ok(koff, pair_band);
     auto column = [&](const u16x2 (&h)[8], const int j) {
         unsigned sel = 0;
         int state = K16_DECIDED;
@@ -236,7 +238,7 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
             sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
         } else {
             const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
-            state = s.ok ? k16_decide<D, 1>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, ds, p, j, sel) : K16_HANDOVER;
+            state = s.ok ? k16_decide<D, 1>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, j, sel) : K16_HANDOVER;
             if (state == K16_HANDOVER) {
                 if (!k16_hand_over(h, w, p, 1, j, s.ok ? s.th : 0u, lane)) {
                     if (lane == 0) {
@@ -281,7 +283,7 @@ __global__ __launch_bounds__(64) void select_fix_side16_kernel(const double *__r
     uint64_t *thr = dir ? w.col_thr + (int64_t)p * w.max_n : w.row_thr + (int64_t)p * w.max_m;
     int *cut = dir ? w.col_cut + (int64_t)p * w.max_n : w.row_cut + (int64_t)p * w.max_m;
     unsigned h_lo, h_hi;
-    k16_reach(th, koff[p], w.band + 2 * p, h_lo, h_hi);
+    k16_reach(th, koff[p], k16_reach_adjacent_ok(koff[p], w.band + 2 * p), w.band + 2 * p, h_lo, h_hi);
     if (dir == 0) {
         if (fix_row_band_range<0, 16>(sm, key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) return;
         fix_row_generic_range<0, 16>(key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
@@ -321,7 +323,7 @@ __global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__re
                 return (unsigned)keys16[ds.crp_off + (DIR == 0 ? (int64_t)which * ds.crp_pitch + q : (int64_t)q * ds.crp_pitch + which)];
             };
             unsigned h_lo, h_hi;
-            k16_reach((unsigned)(thr[which] >> 32), koff[p], w.band + 2 * p, h_lo, h_hi);
+            k16_reach((unsigned)(thr[which] >> 32), koff[p], k16_reach_adjacent_ok(koff[p], w.band + 2 * p), w.band + 2 * p, h_lo, h_hi);
             if (fix_row_band_range<DIR, 16>(sm, key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane)) continue;
             fix_row_generic_range<DIR, 16>(key_at, h_lo, h_hi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane);
         }
@@ -368,17 +370,23 @@ extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float 
     const int rb = ceil_div(max_m, 4 * K16_ROWS_PER_WAVE), cb = ceil_div(max_n, K16_COLS);
     if ((int64_t)K * rb > 0x7fffffffLL || (int64_t)K * cb > 0x7fffffffLL) { set_error("mask_bits_keys16_batch: batch too large"); return ACOSS_ENOTSUP; }
     int rc = ACOSS_OK;
+    auto rows = [&](unsigned blocks, hipStream_t s) {
+        if (d == 12) hipLaunchKernelGGL(select_rows_k16_kernel<12>, dim3(blocks), dim3(256), 0, s, keys16, descs, win, kv, mode, w, rb, cx);
+        else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3(blocks), dim3(256), 0, s, keys16, descs, win, kv, mode, w, rb, cx);
+        return launch_check("select_rows_k16_kernel");
+    };
+    auto cols = [&](hipStream_t s) {
+        if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, s, keys16, descs, win, kv, mode, w, cb, cx);
+        else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, s, keys16, descs, win, kv, mode, w, cb, cx);
+        return launch_check("select_cols_k16_kernel");
+    };
     if (mutual != 3) {                          // (3 = measurement: the column selection kernel alone)
-        if (d == 12) hipLaunchKernelGGL(select_rows_k16_kernel<12>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
-        else hipLaunchKernelGGL(select_rows_k16_kernel<13>, dim3((unsigned)((int64_t)K * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx);
-        rc = launch_check("select_rows_k16_kernel");
+        rc = rows((unsigned)((int64_t)K * rb), st);
         if (rc) return rc;
     }
     if (mutual == 2) return ACOSS_OK;           // measurement: the row selection kernel alone (bench.py's roofline_selection)
     if (mutual) {
-        if (d == 12) hipLaunchKernelGGL(select_cols_k16_kernel<12>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
-        else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx);
-        rc = launch_check("select_cols_k16_kernel");
+        rc = cols(st);
         if (rc) return rc;
         if (mutual == 3) return ACOSS_OK;
     }

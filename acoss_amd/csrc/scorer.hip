@@ -358,7 +358,7 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
                         if ((double)f < w2) f = nextafterf(f, INFINITY);
                         uint32_t fb;
                         memcpy(&fb, &f, 4);
-                        hk[t] = (std::isfinite(f) && f > 7.9e-31f) ? fb - (7u << 23) : 0u;
+                        hk[t] = (std::isfinite(f) && f > 0x1p-100f)      /* the same limit as engine.keys16_koff */ ? fb - (7u << 23) : 0u;
                     }
                     ACOSS_HIP(hipMemcpyAsync(d_koff, hk, 4 * (size_t)B, hipMemcpyHostToDevice, st));
                     if (!rc) rc = acoss_crp_keys16_batch(xp, c->f32, c->n32, c->d, d_descs, B, win, b.max_nx, b.max_ny, d_koff, (uint16_t *)(base + v.T), st);

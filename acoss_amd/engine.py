@@ -209,6 +209,20 @@ def csm_strip(corpus, batch, xp, out=None):
     return out
 
 
+def csm_rows(corpus, batch, xp, out=None):
+    """CRPUtils.py:67 for float64 features through the row-band matrix-core kernel (csrc/csm_rows_kernels.hip): the same
+    matrix as csm / csm_packed / csm_strip, bit for bit; the HBM-bound form (whole-line stores straight from the accumulators)."""
+    lib = _lib.load()
+    if corpus.dtype != np.float64:
+        raise AcossError("csm_rows: float64 features only")
+    if out is None:
+        out = torch.empty(max(batch.total_csm, 1), dtype=torch.float64, device=corpus.device)
+    check(lib.acoss_csm_rows_batch_f64(_ptr(xp), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                       _ptr(batch.descs_dev), batch.K, batch.max_nx, batch.max_ny, _ptr(out),
+                                       _stream()), "csm_rows_batch")
+    return out
+
+
 def crp(corpus, batch, xp, sqrt_out=False, out=None, force_valu=False, force_tile=False):
     """get_csm + sliding_csm fused (CRPUtils.py:67 + :24): windowed sums of squared distances
     (sqrt_out=False) or their square roots = sliding_csm's output (sqrt_out=True); float64."""

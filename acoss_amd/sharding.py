@@ -34,7 +34,7 @@ def shard_indices(costs, world_size, rank):
     return np.sort(order[owner == rank])
 
 
-def gather_scores(local_scores, local_idx, K, group=None, index_of_rank=None):
+def gather_scores(local_scores, local_idx, K, group=None, index_of_rank=None, force_collective=False):
     """
     All-gather of per-rank score vectors into the full length-K vector (on every rank): the path's ONE collective.
     local_scores: float tensor (n_local,) on this rank's device (GPU for nccl, CPU for gloo);
@@ -43,8 +43,16 @@ def gather_scores(local_scores, local_idx, K, group=None, index_of_rank=None):
     function of (costs, world_size, rank), so every rank can name every other rank's positions and only the scores
     travel; without it the positions ride along (as int64 bit patterns in a second half of the message).
     Shards are padded to a common length so that one all_gather_into_tensor moves everything.
+    force_collective: run the collective even in a one-rank group (the one-GPU box's way of proving that RCCL loads, the
+    communicator forms and the gather runs on device tensors: tests/test_gpu_rccl.py); needs an initialised group.
     """
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+    if not (dist.is_available() and dist.is_initialized()):
+        if force_collective:
+            raise RuntimeError("gather_scores(force_collective=True) needs an initialised torch.distributed group")
+        world1 = True
+    else:
+        world1 = dist.get_world_size(group) == 1 and not force_collective
+    if world1:
         out = torch.zeros(K, dtype=local_scores.dtype, device=local_scores.device)
         out[torch.as_tensor(local_idx, device=local_scores.device, dtype=torch.long)] = local_scores
         return out

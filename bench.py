@@ -53,8 +53,11 @@ F64_MATRIX_PEAK_TFLOPS = 78.6   # v_mfma_f64_16x16x4_f64: 128 flop / clk / CU x 
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default 20; 3 with --strong, where a step is the whole job)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed steps (default 3; 1 with --strong)")
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: the FIXED job (all pairs of the corpus: 499 500 at the default size) sharded over the N ranks -- shard -> "
+                         "batches -> one all-gather -> Ds on rank 0; a step is the whole job, value = pairs / wall")
     ap.add_argument("--pairs-per-step", type=int, default=4096,
                     help="pairs per launch batch and GPU (4096 x 3.9 MB of keys = 16 GB of the 288 GB)")
     ap.add_argument("--songs", type=int, default=1000)
@@ -69,7 +72,14 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no comparison paths, no config 3-5 blocks)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = auto)")
-    return ap.parse_args()
+    ap.add_argument("--config3-rank", default=None, metavar="OUT.json",
+                    help="(internal) run the BASELINE config-3 job as one rank of a torch.distributed group and have rank 0 write its summary")
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 3 if args.strong else 20
+    if args.warmup is None:
+        args.warmup = 1 if args.strong else 3
+    return args
 
 
 STAGES = {p: ["oti", "pack_x", "crp", "mask_bits", "qmax_bits"] for p in ("fast16", "fast32", "fast", "fast_f64", "fused")}
@@ -390,6 +400,65 @@ def attach_profile_averages(out, P, args):
                                 "source": "profiles/r03_pmc.json (rocprofv3 --pmc passes of the same command; fractions of the kernel's cycles on the 1024 SIMDs)"}
 
 
+def config3_job(tmpdir, alignments=("qmax", "dmax", "swc")):
+    """BASELINE config 3 at job scale through the plugin: the 2000-song DA-TACOS-shaped corpus (synth.config3: cliques of 13 +
+    singletons, lengths ~N(520, 120) in [200, 1200]; 1 999 000 pairs), Serra09(alignments=qmax, dmax, swc).all_pairwise
+    (sharded over the ranks of the process group when there is one, one all-gather per key), Ds += Ds.T, getEvalStatistics on
+    the GPU for the three chroma keys.  Returns wall seconds, the statistics and a CRC of every chroma score matrix."""
+    import contextlib
+    import io
+    import warnings
+    import zlib
+    import torch
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    ch = synth.config3(n_cliques=133, singletons=271)
+    cwd = os.getcwd()
+    os.chdir(tmpdir)
+    try:
+        with contextlib.redirect_stdout(io.StringIO()), warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            alg = Serra09(ch, shortname="bench_config3_r%s" % os.environ.get("RANK", "0"), do_memmaps=False,
+                          cachedir=os.path.join(tmpdir, "cache_r%s" % os.environ.get("RANK", "0")), alignments=alignments)
+            alg.similarity(synth.all_pairs(ch.n_songs)[:8192].astype(np.int64))          # warm: device corpus, scratch, float32 copy
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            keys = ["chroma_%s" % a for a in alg.alignments]
+            stats = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=True) for k in keys}
+            t2 = time.perf_counter()
+    finally:
+        os.chdir(cwd)
+    K = ch.n_songs * (ch.n_songs - 1) // 2
+    return {"songs": int(ch.n_songs), "pairs": int(K), "alignments": list(alg.alignments),
+            "all_pairwise_seconds": round(t1 - t0, 3), "eval_seconds": round(t2 - t1, 3),
+            "pairs_per_s": round(K / (t2 - t0), 1), "pair_scores_per_s": round(len(keys) * K / (t2 - t0), 1),
+            "MAP": {k: float(stats[k][3]) for k in keys}, "MR": {k: float(stats[k][0]) for k in keys},
+            "Ds_crc32": {k: int(zlib.crc32(np.ascontiguousarray(alg.Ds[k], dtype=np.float32).tobytes())) for k in keys}}
+
+
+def config3_rank_main(out_path):
+    """One rank of the sharded config-3 job (started by extras_config3 through torch.distributed.run; the ranks share the
+    box's GPU, so the gather goes through gloo -- with one GPU per rank the backend is "nccl" = RCCL)."""
+    import tempfile
+    import torch
+    import torch.distributed as dist
+    backend = os.environ.get("ACOSS_BENCH_DIST_BACKEND", "gloo")
+    local = int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1)
+    torch.cuda.set_device(local)
+    dist.init_process_group(backend)
+    res = config3_job(tempfile.mkdtemp(prefix="acoss_c3_"))
+    res["world"] = dist.get_world_size()
+    res["backend"] = backend
+    if dist.get_rank() == 0:
+        with open(out_path, "w") as fh:
+            json.dump(res, fh)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def extras_config3(engine, synth, oracle, threads, torch):
     """BASELINE config 3 (DA-TACOS benchmark_subset shape, Serra09 with constrained Smith-Waterman): a 2000-song sample of
     synth.config3's distribution, qmax + dmax + swc through the one-call scorer."""
@@ -415,7 +484,50 @@ def extras_config3(engine, synth, oracle, threads, torch):
         M, N = B.shape
         D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
         sw_err = max(sw_err, abs(got["swc"][t] - oracle.swconstrained(np.ascontiguousarray(B.flatten()), D, M, N) / (M + N)))
-    return {"workload": "%d songs (synth.config3 distribution: cliques of 13 + singletons, lengths ~N(520,120) in [200,1200]), "
+    del corpus
+    engine.release_scratch()
+    # the whole job through the plugin, on one rank and sharded over four (sharing this GPU; gloo for the gather)
+    import subprocess
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix="acoss_c3_")
+    job = {"call": "Serra09(alignments=('qmax','dmax','swc')).all_pairwise(symmetric=True) + getEvalStatistics(on_gpu=True) x 3 keys"}
+    try:
+        one = config3_job(tmp)
+        job.update(one)
+        engine.release_scratch()
+        torch.cuda.empty_cache()
+        import socket
+        sk = socket.socket()
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+        sk.close()
+        outp = os.path.join(tmp, "ranks4.json")
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        env["ACOSS_BENCH_DIST_BACKEND"] = "gloo"
+        t0 = time.perf_counter()
+        res = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr", "127.0.0.1",
+                              "--master-port", str(port), os.path.abspath(__file__), "--config3-rank", outp],
+                             env=env, capture_output=True, text=True, timeout=900)
+        if res.returncode == 0 and os.path.exists(outp):
+            with open(outp) as fh:
+                four = json.load(fh)
+            job["sharded_4_ranks"] = {"world": four["world"], "backend": four["backend"] + " (4 ranks sharing the one GPU)",
+                                      "all_pairwise_seconds": four["all_pairwise_seconds"], "pairs_per_s": four["pairs_per_s"],
+                                      "wall_seconds_with_process_start": round(time.perf_counter() - t0, 1)}
+            job["identical_1_vs_4_ranks"] = bool(four["Ds_crc32"] == one["Ds_crc32"] and four["MAP"] == one["MAP"])
+        else:
+            job["sharded_4_ranks"] = {"error": (res.stderr or res.stdout)[-600:]}
+            job["identical_1_vs_4_ranks"] = None
+    except Exception as exc:
+        job["error"] = "%s: %s" % (type(exc).__name__, exc)
+    finally:
+        import shutil
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"job": job,
+            "workload": "%d songs (synth.config3 distribution: cliques of 13 + singletons, lengths ~N(520,120) in [200,1200]), "
                         "%d random pairs, Serra09 qmax + dmax + constrained Smith-Waterman (EarlySNF_Old.py:198-218) per pair" % (ch.n_songs, len(pairs)),
             "value": round(len(pairs) / el, 1), "unit": "pair-scores/s (3 recurrences per pair)", "seconds": round(el, 3),
             "cpu_baseline": {"value": round(n_cpu / cpu_s, 2), "unit": "pair-scores/s (qmax + dmax)", "cores": int(used), "kind": "port",
@@ -551,6 +663,26 @@ def extras_full_job(corpus_h, torch, tmpdir):
                                        "map_equals_reference": bool(same_stats),
                                        "fixture": "tests/golden/config2_slice64.npz (reference chain + reference getEvalStatistics)"}
         del alg
+        # the same on a slice whose covers are hard enough for the statistics to discriminate (synth.config2_hard(): the
+        # reference's MAP is 0.78, not 1.0); the host argsort form reproduces the reference's tie order, the GPU ranks
+        # equal scores in song-index order (CoverAlgorithm.getEvalStatistics)
+        gh = np.load(os.path.join(ROOT, "tests", "golden", "config2_hard64.npz"))
+        hc = synth.config2_hard()
+        with contextlib.redirect_stdout(io.StringIO()):
+            alg = Serra09(hc, shortname="bench_hard", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
+            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            hs = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=False) for k in ("chroma_qmax", "chroma_dmax")}
+            hs_gpu = alg.getEvalStatistics("chroma_qmax", verbose=False, write_csv=False, on_gpu=True)
+        hp = synth.all_pairs(hc.n_songs)
+        h_scores = all(np.array_equal(np.asarray(alg.Ds[k])[hp[:, 0], hp[:, 1]], gh[k].astype(np.float32)) for k in ("chroma_qmax", "chroma_dmax"))
+        h_stats = all(np.array_equal(np.array(list(hs[k][:4]) + list(hs[k][4])), gh["stats_" + k.split("_")[1]]) for k in ("chroma_qmax", "chroma_dmax"))
+        out["hard_slice"] = {"pairs": int(len(hp)), "scores_identical": bool(h_scores), "MAP": float(hs["chroma_qmax"][3]),
+                             "reference_MAP": float(gh["stats_qmax"][3]), "MAP_dmax": float(hs["chroma_dmax"][3]),
+                             "reference_MAP_dmax": float(gh["stats_dmax"][3]), "map_equals_reference": bool(h_stats),
+                             "MAP_ranks_on_gpu": float(hs_gpu[3]),
+                             "fixture": "tests/golden/config2_hard64.npz (synth.config2_hard(): noise U(0, 1.5), tempo 0.5 .. 2.0; reference "
+                                        "chain + reference getEvalStatistics)"}
+        del alg
         with contextlib.redirect_stdout(io.StringIO()):
             alg = Serra09(corpus_h, shortname="bench_full", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
             alg.all_pairwise(symmetric=True, batch_pairs=65536)          # warm: device corpus, scratch of the final size
@@ -568,7 +700,7 @@ def extras_full_job(corpus_h, torch, tmpdir):
                     "value": round(K / (t2 - t0), 1), "unit": "pairs/s end to end (two recurrences per pair)",
                     "MAP_chroma_qmax": float(res["chroma_qmax"][3]), "MAP_chroma_dmax": float(res["chroma_dmax"][3]),
                     "MR_chroma_qmax": float(res["chroma_qmax"][0]), "top1_chroma_qmax": float(res["chroma_qmax"][4][0]),
-                    "map_equals_reference": bool(same_stats and same_scores)})
+                    "map_equals_reference": bool(same_stats and same_scores and h_stats and h_scores)})
         return out
     finally:
         os.chdir(cwd)
@@ -644,8 +776,68 @@ def extras_scatter_chain(engine, oracle, torch):
                        "identical": bool(g1["qmax"][0] == q and g1["dmax"][0] == d), "scores_nonzero": bool(np.any(got["qmax"] > 0))}}
 
 
+def strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use_dist, m, kappa):
+    """--strong: the fixed job -- every pair of the corpus (499 500 at the default 1000 songs), chroma_qmax -- sharded over the
+    ranks as CoverAlgorithm.all_pairwise shards it (CoverAlgorithm.py:166-182 is the reference's joblib form): cost-sorted
+    snake deal -> the rank's shard through the one-call scorer (its own batches inside) -> ONE all-gather of the score
+    vectors -> Ds (N x N, Ds += Ds.T) on rank 0.  A step is the whole job; per step: barrier + synchronize on both sides,
+    max over ranks; value = steps x pairs / that time.  `scores_crc32` lets two runs (1 rank against N) be compared."""
+    import zlib
+    import torch
+    import torch.distributed as dist
+    from acoss_amd import engine, sharding
+    K = len(all_pairs)
+    costs = sharding.pair_costs(corpus_h.frame_off, all_pairs, m)
+    shards = [sharding.shard_indices(costs, world, r) for r in range(world)]
+    mine = shards[rank]
+    my_pairs = np.ascontiguousarray(all_pairs[mine])
+    cdev = dev if backend == "nccl" else torch.device("cpu")
+
+    def sync():
+        torch.cuda.synchronize()
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+    engine.serra09_scores(corpus, my_pairs[:min(len(my_pairs), 16384)], m=m, kappa=kappa, want=("qmax",))     # scratch, float32 copy
+    elapsed, full, Ds, shard_s = 0.0, None, None, 0.0
+    for rep in range(args.warmup + args.steps):
+        sync()
+        t0 = time.perf_counter()
+        got = engine.serra09_scores(corpus, my_pairs, m=m, kappa=kappa, want=("qmax",))
+        t1 = time.perf_counter()
+        local = torch.from_numpy(got["qmax"]).to(cdev)
+        full = sharding.gather_scores(local, mine, K, index_of_rank=lambda r: shards[r], force_collective=use_dist)
+        if rank == 0:
+            Ds = sharding.scatter_to_matrix(all_pairs, full.cpu().numpy(), corpus_h.n_songs, symmetric=True)
+        sync()
+        if rep >= args.warmup:
+            elapsed += time.perf_counter() - t0
+            shard_s += t1 - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    host = np.ascontiguousarray(full.cpu().numpy().astype(np.float64))
+    return {"metric": "pair-scores/sec (Serra09 qmax, 1000-frame HPCP)", "value": round(args.steps * K / elapsed, 1), "unit": "pair-scores/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f32 filter (16-bit keys) + f64 exact refinement (results identical to f64)", "data": "synthetic",
+            "config": {"workload": "the whole job: all %d pairs of synthetic %d songs x %d frames x 12-bin HPCP (f64), Serra09 chroma_qmax m=9 "
+                                   "kappa=0.095 OTI, sharded over %d rank(s); a step = the job" % (K, args.songs, args.frames, world),
+                       "pairs_per_rank": int(len(mine)), "parallelism": "pair-shard x%d (cost-sorted snake deal), one all-gather, Ds on rank 0" % world,
+                       "collective": ({"backend": dist.get_backend(), "world": world, "ran": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
+                                      if use_dist else None)},
+            "rank0_scorer_seconds_per_step": round(shard_s / args.steps, 4),
+            "scores_crc32": int(zlib.crc32(host.tobytes())), "scores_sum": float(host.sum()),
+            "Ds_symmetric": bool(Ds is not None and np.array_equal(Ds, Ds.T)),
+            "roofline": None, "cpu_baseline": None,
+            "note": "strong-scaling mode of the same path; the weak-scaling default line carries roofline / cpu_baseline / parity"}
+
+
 def main():
     args = parse()
+    if args.config3_rank:
+        return config3_rank_main(args.config3_rank)
     if args.gpus < 1:
         sys.exit("bench.py: --gpus must be >= 1")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
@@ -666,16 +858,33 @@ def main():
         local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # ACOSS_BENCH_FORCE_DIST=1: form the process group and run every collective of this file in a ONE-rank group too (what a
+    # one-GPU box can prove about the RCCL path: librccl loads, the communicator forms, all_gather_into_tensor / all_reduce /
+    # barrier run on device tensors: tests/test_gpu_rccl.py)
+    use_dist = world > 1 or os.environ.get("ACOSS_BENCH_FORCE_DIST", "0") == "1"
+    if use_dist:
+        if "MASTER_ADDR" not in os.environ:
+            import socket
+            sk = socket.socket()
+            sk.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(sk.getsockname()[1]))
+            sk.close()
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     m, kappa = 9, 0.095
     corpus_h = synth.config2(n_songs=args.songs, n_frames=args.frames)
     corpus = engine.DeviceCorpus(corpus_h.feats, corpus_h.frame_off, gchroma=corpus_h.gchroma, device=dev)
     all_pairs = synth.all_pairs(corpus_h.n_songs)
+    if args.strong:
+        out = strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use_dist, m, kappa)
+        if rank == 0:
+            print(json.dumps(out))
+        if use_dist:
+            dist.destroy_process_group()
+        return
     costs = sharding.pair_costs(corpus_h.frame_off, all_pairs, m)
     mine = sharding.shard_indices(costs, world, rank)
     P = args.pairs_per_step
@@ -689,7 +898,7 @@ def main():
     events = [[torch.cuda.Event(enable_timing=True) for _ in range(6)] for _ in range(n_steps)]
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
 
     for s in range(args.warmup):
@@ -703,7 +912,7 @@ def main():
     # the path's only collective: gather every rank's timed scores (RCCL all-gather over xGMI)
     timed_idx = np.concatenate(step_idx[args.warmup:])
     local = scores[args.warmup:].reshape(-1)
-    if world > 1:
+    if use_dist:
         src = local if backend == "nccl" else local.cpu()
         gathered = torch.empty(world * local.numel(), dtype=local.dtype, device=src.device)
         dist.all_gather_into_tensor(gathered, src)
@@ -714,7 +923,7 @@ def main():
     barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -768,7 +977,9 @@ def main():
                                % (args.songs, args.frames, P, len(all_pairs)),
                    "path": args.path, "pairs_per_step_per_gpu": P,
                    "output_placement_probe_ms": runner.placement_ms,
-                   "parallelism": "pair-shard x%d, one all-gather" % world},
+                   "parallelism": "pair-shard x%d, one all-gather" % world,
+                   "collective": ({"backend": dist.get_backend(), "world": world, "ran": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
+                                  if use_dist else None)},
         "roofline": {"kernel": kname, "bound": bound,
                      "achieved": round(achieved, 1), "peak": peak, "unit": unit,
                      "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
@@ -784,7 +995,10 @@ def main():
         C = torch.empty(b.total_csm, dtype=corpus.feats.dtype, device=dev)
         cb = runner.csm_bytes[-1]
         xp = engine.pack_x(corpus, b)
-        for key, kname2, fn in (("roofline_csm_materialising", "crp_strip_kernel<12,1,sqrt> as get_csm (CRPUtils.py:67), not on the fast path",
+        for key, kname2, fn in (("roofline_csm_materialising", "csm_rows_kernel<12> = get_csm (CRPUtils.py:67-84) in row-band form, float64 out "
+                                 "(8 B / cell; not on the fast path, which never writes a CSM)",
+                                 lambda: engine.csm_rows(corpus, b, xp, out=C)),
+                                ("roofline_csm_strip", "crp_strip_kernel<12,1,sqrt> as get_csm (CRPUtils.py:67): rounds 1-3's form, column strips",
                                  lambda: engine.csm_strip(corpus, b, xp, out=C)),
                                 ("roofline_csm_valu", "csm_kernel<double,12> (CRPUtils.py:67), not on the fast path",
                                  lambda: engine.csm(corpus, b, out=C))):
@@ -865,7 +1079,13 @@ def main():
         out["cpu_baseline"] = {"value": round(n_cpu / cpu_s, 2), "unit": "pair-scores/s", "cores": int(used),
                                "kind": "port",
                                "sample": "%d pairs of the same workload through oracle/acoss_oracle.c "
-                                         "(OpenMP over pairs, %.1f s)" % (n_cpu, cpu_s)}
+                                         "(OpenMP over pairs, %.1f s)" % (n_cpu, cpu_s),
+                               # the reference itself cannot travel to the GPU box; its own chain (CRPUtils.py + pySeqAlign built
+                               # -Ofast) was timed where it lives, BASELINE.md section 3 -- quoted, not measured by this run
+                               "reference_chain_in_build_container": {
+                                   "value_1_process": 5.15, "value_8_processes": 36.5, "unit": "pair-scores/s", "cores": 8,
+                                   "kind": "reference", "source": "BASELINE.md section 3: Serra09 chain of /root/reference on the build "
+                                                                    "container's 8 vCPUs (Xeon @ 2.1 GHz), 1000-frame pairs"}}
         out["parity"] = {"checked_pairs": int(n_cpu), "identical": bool(np.array_equal(gpu_q, q_cpu))}
         # beside it: the reference's own SequenceAlignment.c (compiled in place by oracle/Makefile into oracle/_ref,
         # -Ofast as in its setup.py) on the alignment step alone -- qmax_c over the same masks, one call per pair,
@@ -972,10 +1192,12 @@ def main():
                 out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
             engine.release_scratch()
             torch.cuda.empty_cache()
+        import shutil
+        shutil.rmtree(tmpdir, ignore_errors=True)
     if rank == 0:
         attach_profile_averages(out, P, args)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

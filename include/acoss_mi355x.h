@@ -186,12 +186,19 @@ int acoss_csm_packed_batch_f32(const float *xp, const float *feats, const float 
 int acoss_csm_strip_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                               const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm,
                               void *stream);
+/* get_csm (CRPUtils.py:67-84) in row-band form (round 4; csrc/csm_rows_kernels.hip): the same arguments and bit for bit the
+ * same matrix as acoss_csm_strip_batch_f64 -- x stationary in registers, y streaming, no shared memory; every wave store
+ * writes four rows x 256 contiguous line-aligned bytes straight from the matrix-core accumulators (non-temporal).  The
+ * HBM-bound kernel of the library: 8 bytes written per cell. */
+int acoss_csm_rows_batch_f64(const double *xp, const double *feats, const double *norms, int d,
+                             const acoss_pair_desc *descs, int K, int max_nx, int max_ny, double *csm,
+                             void *stream);
 int acoss_crp_batch_f64(const double *xp, const double *feats, const double *norms, int d,
                         const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, int sqrt_out,
                         double *out, void *stream);
 /* Float32 approximation of acoss_crp_planar_batch_f64's matrix (xp, feats, norms: the float64 corpus rounded to
  * float32, packed by acoss_pack_x_f32): the windowed sums computed in float32 and written as order-preserving uint32
- * keys (the float32 bit pattern with the sign bit set), same element indexing.  |approx - exact| <= 2^-24 * (16.5 *
+ * keys (the float32 bit pattern with the sign bit set), same element indexing.  |approx - exact| <= 2^-24 * ((d + 4.5) *
  * (sum over the window of |x_{i+k}|^2 + |y_{j+k}|^2) + 9.5 * exact).  CRPUtils.py:67-84 + :24-45, d in {12, 13}, win == 9. */
 int acoss_crp_planar32_batch(const float *xp, const float *feats, const float *norms, int d,
                              const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
@@ -269,7 +276,7 @@ int acoss_mask_bits_planar_batch(const uint32_t *planes, const double *feats, co
                                  void *work, size_t work_bytes, void *stream);
 /* acoss_mask_bits_planar_batch on the float32-approximate keys of acoss_crp_planar32_batch.  band holds two floats per
  * pair, (base, slope): twice the error bound of an approximate value v of pair p is band[2p] + band[2p+1] * v
- * (base = 2 * 16.5 * 2^-24 * (largest window sum of squared norms of song x + of song y), slope = 2 * 9.5 * 2^-24, both
+ * (base = 2 * (d + 4.5) * 2^-24 * (largest window sum of squared norms of song x + of song y), slope = 2 * 9.5 * 2^-24, both
  * rounded up; derivation in DESIGN.md section 4).  A row / column whose k-th smallest approximate value has another
  * value within that distance is finished in float64: the values inside the band are recomputed exactly from feats /
  * norms (the float64 corpus), the rest is decided by the approximation.  The masks equal
@@ -282,7 +289,8 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
  * sums of acoss_crp_planar32_batch leave the chip as ONE uint16 per cell,
  *     k' = float32 bits -saturating koff[pair],   key16 = min(max(k' >> 11, (k' >> 9) -saturating 49152), 0xFFFE),
  *     koff[pair] = bit pattern of 2 W_pair 2^-7 (of the float32 not below 2 W_pair)
- * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * 16.5 * 2^-24) of `band`; no
+ * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * (d + 4.5) * 2^-24) of `band`; the kernels check
+ * per pair that `band` and `koff` agree in this sense and fall back to the float evaluation of the reach where they do not; no
  * windowed sum exceeds 2 W_pair): 14 mantissa bits over the three octaves below 2 W_pair, 12 over the four below those, one
  * monotone map; same element indexing as the uint32 matrix (element = 2 bytes).
  * acoss_mask_bits_keys16_batch selects on those keys; where the winner's error band can reach another key it recomputes

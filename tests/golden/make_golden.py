@@ -210,6 +210,36 @@ def gen_serra09_mini():
     print("serra09_mini.npz")
 
 
+def gen_serra09_swc():
+    """BASELINE config 3, "Serra09 Smith-Waterman constrained", at chain level: the Serra09 chain of the 12-song mini-corpus
+    (Serra09.py:166-171: oti, roll, get_csm, sliding_csm, csm_to_binary_mutual -- the reference's CRPUtils functions) with the
+    reference's compiled swalignimpconstrained as the alignment, called the way its one caller does (EarlySNF_Old.py:198-203:
+    D = zeros((M+1)*(N+1)), alignment_fn(mask.flatten(), D, M, N), rows first).  Raw scores and the mask shapes; the plugin's
+    `chroma_swc` key is raw / (M + N), the normalisation Serra09 applies to its other alignments (Serra09.py:174-175).
+    Same corpus and pair list as serra09_mini.npz (that fixture holds the features)."""
+    corpus = synth.make_corpus(4, 3, seed=1212, lengths=lambda r: r.integers(60, 141))
+    n = corpus.n_songs
+    pairs = [(i, j) for i in range(n) for j in range(i + 1, n)] + [(3, 3), (7, 2), (11, 0)]
+    pairs = np.array(pairs, dtype=np.int32)
+    raw, one_sided, shapes = np.zeros(len(pairs)), np.zeros(len(pairs)), np.zeros((len(pairs), 2), dtype=np.int64)
+    for t, (i, j) in enumerate(pairs):
+        dump = {}
+        chain(corpus.song(i), corpus.gchroma[i], corpus.song(j), corpus.gchroma[j], 9, 0.095, True, dump)
+        B = dump["B"]
+        M, N = B.shape
+        D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        raw[t] = ref_swc(np.ascontiguousarray(B.flatten()), D, M, N)
+        B1 = ref.csm_to_binary(dump["S"], 0.095)                   # the one-sided mask EarlySNF_Old.py:201 aligns
+        D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+        one_sided[t] = ref_swc(np.ascontiguousarray(B1.flatten()), D, M, N)
+        shapes[t] = (M, N)
+    import zlib
+    np.savez_compressed(os.path.join(HERE, "serra09_swc.npz"), meta=meta(), pairs=pairs, shapes=shapes,
+                        corpus_crc=np.array([zlib.crc32(corpus.feats.tobytes())]),
+                        chroma_swc_raw=raw, chroma_swc=raw / shapes.sum(axis=1), onesided_swc_raw=one_sided)
+    print("serra09_swc.npz", raw[:5], one_sided[:5])
+
+
 def gen_pairs_1000():
     """Three 1000-frame pairs of the BASELINE config-2 generator (cover / cover / non-cover)."""
     corpus = synth.make_corpus(3, 2, n_frames=1000, seed=20260)
@@ -327,10 +357,15 @@ def gen_config1():
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--config1", action="store_true", help="also run the slow config-1 corpus")
+    ap.add_argument("--swc-only", action="store_true", help="only serra09_swc.npz (round 4)")
     args = ap.parse_args()
+    if args.swc_only:
+        gen_serra09_swc()
+        sys.exit(0)
     gen_stages()
     gen_dp()
     gen_serra09_mini()
+    gen_serra09_swc()
     gen_pairs_1000()
     gen_evalstats()
     if args.config1:

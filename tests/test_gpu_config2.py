@@ -34,6 +34,44 @@ def test_config2_slice_all_pairwise_scores_and_map_equal_reference(golden, tmp_p
     alg.cleanup_memmap()
 
 
+def test_hard_slice_scores_and_statistics_equal_reference(golden, tmp_path, monkeypatch):
+    """"MAP vs ref" where MAP discriminates: synth.config2_hard() -- 64 songs of config 2's shape with heavier noise and a wider
+    tempo spread, on which the reference's MAP is 0.6-0.9 instead of 1.0 -- through Serra09.all_pairwise: all 2 016 scores of
+    both keys and (MR, MRR, MDR, MAP, Top-k) array_equal the reference's (tests/golden/config2_hard64.npz), ranks from the host
+    argsort and from the GPU."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    monkeypatch.chdir(tmp_path)
+    g = golden("config2_hard64")
+    corpus = synth.config2_hard()
+    assert zlib.crc32(corpus.feats.tobytes()) == int(g["corpus_crc"][0])
+    assert 0.6 <= float(g["stats_qmax"][3]) <= 0.9                              # the statistic has room to move
+    alg = Serra09(corpus, shortname="config2hard", do_memmaps=True, cachedir=str(tmp_path / "cache"))
+    alg.all_pairwise(symmetric=True)
+    pairs = synth.all_pairs(corpus.n_songs)
+    for key in ("chroma_qmax", "chroma_dmax"):
+        got = np.asarray(alg.Ds[key])[pairs[:, 0], pairs[:, 1]]
+        assert np.array_equal(got, g[key].astype(np.float32)), key
+    labels = np.array(corpus.labels)
+    for key, want in (("chroma_qmax", g["stats_qmax"]), ("chroma_dmax", g["stats_dmax"])):
+        MR, MRR, MDR, MAP, tops = alg.getEvalStatistics(key, verbose=False, write_csv=False, on_gpu=False)
+        assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), want), key          # the reference's argsort, its tie order
+        # on the GPU equal scores rank in song-index order (the reference's unstable argsort leaves ties unspecified, and this
+        # slice has them: alignment values are multiples of 0.5): the ranks must be exactly that order's, and the statistics
+        # they give stay within the ties' reach of the reference's
+        D = np.array(alg.Ds[key], dtype=np.float32)
+        cliques = [sorted(v) for v in alg.cliques.values()]
+        ranks, off = alg._mate_ranks_device(D, cliques)
+        for i in range(corpus.n_songs):
+            mates = np.flatnonzero((labels == labels[i]) & (np.arange(corpus.n_songs) != i))
+            k = np.arange(corpus.n_songs)
+            expect = sorted(1 + int(np.sum((k != i) & ((D[i] > D[i, j]) | ((D[i] == D[i, j]) & (k < j))))) for j in mates)
+            assert list(ranks[off[i]:off[i + 1]]) == expect, (key, i)
+        got = alg.getEvalStatistics(key, verbose=False, write_csv=False, on_gpu=True)
+        assert abs(got[3] - want[3]) <= 1e-3 and abs(got[0] - want[0]) <= 0.05 and np.array_equal(got[4], want[4:]), (key, got, want)
+    alg.cleanup_memmap()
+
+
 def test_plugin_similarity_equals_the_references_own_similarity(golden, tmp_path):
     """The dict Serra09.similarity returns (chroma with OTI, MFCC without, float32 'ssms' features without window:
     Serra09.py:158-196) against what the reference's own Serra09.similarity returned on the same features."""

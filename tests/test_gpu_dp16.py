@@ -1,5 +1,5 @@
-"""qmax in 16-bit integers (dp_bits_q16_kernel: E = 2 D on packed u16 instructions) against the oracle's qmax_c restatement
-(SequenceAlignment.c:113-143) on masks the selection never produces: dense ones, where the alignment values grow to the
+"""qmax and dmax in 16-bit integers (dp_bits_q16_kernel / dp_bits_d16_kernel: E = 2 D on packed u16 instructions) against the
+oracle's qmax_c / dmax_c restatements (SequenceAlignment.c:113-180) on masks the selection never produces: dense ones, where the alignment values grow to the
 matrix size, all-ones and all-zeros, and every width class (a lane boundary, a register boundary, one column)."""
 import numpy as np
 import pytest
@@ -18,7 +18,7 @@ def _pack(masks, max_m, W=16):
     return out.reshape(-1).view(np.int64)
 
 
-def test_integer_qmax_equals_oracle_on_dense_and_degenerate_masks(orc):
+def test_integer_qmax_and_dmax_equal_oracle_on_dense_and_degenerate_masks(orc):
     import torch
     from acoss_amd import engine
     engine.require_gpu()
@@ -49,3 +49,15 @@ def test_integer_qmax_equals_oracle_on_dense_and_degenerate_masks(orc):
         want = orc.qmax(np.ascontiguousarray(B.reshape(-1)), D, M, N)
         assert got[p] == want, (p, B.shape, got[p], want)
     assert got[len(shapes)] == 1022.0
+    # dmax (dp_bits_d16_kernel; SequenceAlignment.c:147-180) on the same masks: on a fresh D (boundary 0) and on the D that
+    # qmax leaves behind, as Serra09 drives it (Serra09.py:173-175: boundary 1)
+    for boundary in (0, 1):
+        gd = engine.align_bits("dmax", bits, batch, boundary=boundary).cpu().numpy()
+        for p, B in enumerate(masks):
+            M, N = B.shape
+            Bf = np.ascontiguousarray(B.reshape(-1))
+            D = np.zeros(M * N, dtype=np.float32)
+            if boundary:
+                orc.qmax(Bf, D, M, N)
+            want = orc.dmax(Bf, D, M, N)
+            assert gd[p] == want, (boundary, p, B.shape, gd[p], want)

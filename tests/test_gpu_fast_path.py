@@ -37,6 +37,8 @@ def test_fused_kernels_against_reference_stages(eng, golden, c):
     assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C1, batch, 0, "csm"))     # same arithmetic, bit for bit
     C2 = eng.csm_strip(corpus, batch, xp)                                           # matrix-core strip kernel
     assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C2, batch, 0, "csm"))
+    C3 = eng.csm_rows(corpus, batch, xp)                                            # row-band kernel (round 4)
+    assert np.array_equal(_mat(C0, batch, 0, "csm"), _mat(C3, batch, 0, "csm"))
     S = _mat(eng.crp(corpus, batch, xp, sqrt_out=True), batch, 0, "crp")
     assert np.max(np.abs(S - g[p + "S"])) <= 1e-9
     Tbuf = eng.crp(corpus, batch, xp, sqrt_out=False)
@@ -50,6 +52,39 @@ def test_fused_kernels_against_reference_stages(eng, golden, c):
     # selection on the squared sums gives the reference's masks
     assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=False), batch, 0, "crp"), g[p + "B1"])
     assert np.array_equal(_mat(eng.binarize(Tbuf, batch, kappa, mutual=True), batch, 0, "crp"), g[p + "B"])
+
+
+@pytest.mark.parametrize("d", [12, 13])
+def test_row_band_csm_equals_the_valu_kernel_on_ragged_batches(eng, d):
+    """get_csm in row-band form (csm_rows_kernel; CRPUtils.py:67-84) against csm_kernel on a batch of ragged pairs -- lengths
+    1 .. 1000 including non-multiples of every tile size, OTI shifts, d = 12 and 13 -- whole matrices bit for bit, and no
+    byte written outside them (columns past the end of a row and the rows of other pairs keep their fill pattern)."""
+    import torch
+    rng = np.random.default_rng(40 + d)
+    lens = [1, 2, 15, 16, 17, 31, 33, 64, 97, 127, 128, 129, 255, 300, 513, 1000, 999]
+    feats = rng.random((sum(lens), d))
+    off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    corpus = eng.DeviceCorpus(feats, off, gchroma=rng.random((len(lens), 12)) if d == 12 else None)
+    pairs = [(i, j) for i in range(len(lens)) for j in (0, 3, 7, 11, 15, 16) if i != j][:64]
+    for pitch_align in (16, 32):
+        batch = eng.PairBatch(corpus.frame_off, pairs, 1, corpus.device, pitch_align=pitch_align)
+        if d == 12:
+            eng.oti(corpus, batch)
+        xp = eng.pack_x(corpus, batch)
+        want = eng.csm(corpus, batch)
+        fill = float.fromhex("0x1.5p+40")
+        got = torch.full((batch.total_csm,), fill, dtype=torch.float64, device=corpus.device)
+        eng.csm_rows(corpus, batch, xp, out=got)
+        gh, wh = got.cpu().numpy(), want.cpu().numpy()
+        untouched = np.ones(batch.total_csm, dtype=bool)
+        for p in range(batch.K):
+            dsc = batch.descs[p]
+            nx, ny, o, pt = int(dsc["nx"]), int(dsc["ny"]), int(dsc["csm_off"]), int(dsc["csm_pitch"])
+            G = gh[o:o + nx * pt].reshape(nx, pt)
+            W = wh[o:o + nx * pt].reshape(nx, pt)
+            assert np.array_equal(G[:, :ny], W[:, :ny]), (p, nx, ny)
+            untouched[o:o + nx * pt].reshape(nx, pt)[:, :ny] = False
+        assert np.all(gh[untouched] == fill)
 
 
 def test_fused_float32_features(eng, golden):

@@ -170,3 +170,31 @@ def test_songs_longer_than_2056_frames(orc):
             M, N = B.shape
             sw = orc.swconstrained(np.ascontiguousarray(B.flatten()), np.zeros((M + 1) * (N + 1), dtype=np.float32), M, N) / (M + N)
             assert abs(got["swc"][t] - sw) <= 1e-5
+
+
+def test_config3_swc_through_the_plugin(golden, tmp_path):
+    """BASELINE config 3 ("Serra09 Smith-Waterman constrained") through the plugin surface: Serra09(alignments=(..., "swc"))
+    returns and stores `chroma_swc` (and `mfcc_swc`) beside the reference's six keys; values within 1e-5 of the reference's
+    chain (tests/golden/serra09_swc.npz: CRPUtils chain + compiled SequenceAlignment.c as EarlySNF_Old.py:198-203 calls it),
+    the other keys unchanged bit for bit; the default constructor keeps exactly the reference's six keys."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    g, w = golden("serra09_mini"), golden("serra09_swc")
+    corpus = synth.Corpus(g["feats"], g["frame_off"], g["gchroma"], [str(x) for x in g["labels"]])
+    off = g["frame_off"]
+    corpus.mfcc = [np.ascontiguousarray(g["mfcc"][off[i]:off[i + 1]].T) for i in range(corpus.n_songs)]
+    alg = Serra09(corpus, shortname="mini_swc", do_memmaps=True, cachedir=str(tmp_path / "cache"), alignments=("qmax", "dmax", "swc"))
+    assert alg.similarity_types == Serra09.KEYS + ["ssms_scatter_swc", "chroma_swc", "mfcc_swc"]
+    idxs = g["pairs"].astype(np.int64)
+    with pytest.warns(UserWarning):
+        sims = alg.similarity(idxs)
+    assert sorted(sims) == sorted(alg.similarity_types)
+    assert np.array_equal(sims["chroma_qmax"], g["chroma_qmax"]) and np.array_equal(sims["chroma_dmax"], g["chroma_dmax"])
+    assert np.array_equal(sims["mfcc_qmax"], g["mfcc_qmax"]) and np.array_equal(sims["mfcc_dmax"], g["mfcc_dmax"])
+    assert sims["chroma_swc"].dtype == np.float64
+    assert np.max(np.abs(sims["chroma_swc"] - w["chroma_swc"])) <= 1e-5
+    assert np.max(sims["chroma_swc"]) > 0.05 and np.all(sims["mfcc_swc"] >= 0) and np.any(sims["mfcc_swc"] > 0)
+    assert np.allclose(np.asarray(alg.Ds["chroma_swc"])[idxs[:, 0], idxs[:, 1]], w["chroma_swc"].astype(np.float32), rtol=0, atol=1e-5)
+    assert sorted(Serra09(corpus, shortname="mini_d", do_memmaps=False).similarity_types) == sorted(Serra09.KEYS)
+    with pytest.raises(ValueError):
+        Serra09(corpus, shortname="bad", do_memmaps=False, alignments=("qmax", "swc"))

@@ -134,6 +134,27 @@ def test_serra09_mini_chain(orc, golden):
     assert np.array_equal(d, g["chroma_dmax"])
 
 
+def test_serra09_swc_chain(orc, golden):
+    """BASELINE config 3 at chain level: the oracle's chain (stage by stage) + its swalignimpconstrained restatement against the
+    reference's compiled one on the reference's masks (serra09_swc.npz: CRPUtils chain + SequenceAlignment.c -Ofast, called
+    as EarlySNF_Old.py:198-203 does).  The -0.7 penalty is inexact in float32 and -Ofast reassociates: 1e-5."""
+    import zlib
+    g, mini = golden("serra09_swc"), golden("serra09_mini")
+    assert zlib.crc32(np.ascontiguousarray(mini["feats"]).tobytes()) == int(g["corpus_crc"][0])
+    assert np.array_equal(g["pairs"], mini["pairs"])
+    feats, off, gc = mini["feats"], mini["frame_off"], mini["gchroma"]
+    for t, (i, j) in enumerate(g["pairs"][:24]):
+        X, Y = feats[off[i]:off[i + 1]], feats[off[j]:off[j + 1]]
+        S = orc.sliding_csm(orc.get_csm(X, Y, orc.get_oti(gc[i], gc[j])), 9)
+        for key, B in (("chroma_swc_raw", orc.csm_to_binary_mutual(S, 0.095)), ("onesided_swc_raw", orc.csm_to_binary(S, 0.095))):
+            M, N = B.shape
+            assert (M, N) == tuple(g["shapes"][t])
+            D = np.zeros((M + 1) * (N + 1), dtype=np.float32)
+            got = orc.swconstrained(np.ascontiguousarray(B.flatten()), D, M, N)
+            assert abs(got - g[key][t]) <= 1e-5, (t, key, got, g[key][t])
+    assert np.allclose(g["chroma_swc"], g["chroma_swc_raw"] / g["shapes"].sum(axis=1), rtol=0, atol=0)
+
+
 def test_pairs_1000(orc, golden):
     g = golden("pairs_1000")
     feats, off, gc, pairs = g["feats"], g["frame_off"], g["gchroma"], g["pairs"]
@@ -232,6 +253,29 @@ def test_config2_slice_scores_and_map(orc, golden):
         D += D.T
         MR, MRR, MDR, MAP, tops = get_eval_statistics(D, corpus.cliques())
         assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), g["stats_" + key])
+
+
+def test_config2_hard_slice_scores_and_map(orc, golden):
+    """The oracle on the hard slice (synth.config2_hard(): MAP 0.6-0.9 in the reference): a sample of the 2 016 scores of both
+    keys equal the reference's, and the reference's statistics follow from its scores through the loop-form evaluation."""
+    import zlib
+    from acoss_amd import synth
+    from oracle import evalstats
+    g = golden("config2_hard64")
+    corpus = synth.config2_hard()
+    assert zlib.crc32(corpus.feats.tobytes()) == int(g["corpus_crc"][0])
+    pairs = synth.all_pairs(corpus.n_songs)
+    sel = np.random.default_rng(3).permutation(len(pairs))[:96]
+    q, d, _ = orc.serra09_pairs(corpus.feats, corpus.frame_off, corpus.gchroma, pairs[sel], nthreads=8)
+    assert np.array_equal(q, g["chroma_qmax"][sel]) and np.array_equal(d, g["chroma_dmax"][sel])
+    n = corpus.n_songs
+    for key, want in (("chroma_qmax", g["stats_qmax"]), ("chroma_dmax", g["stats_dmax"])):
+        D = np.zeros((n, n), dtype=np.float32)
+        D[pairs[:, 0], pairs[:, 1]] = g[key]
+        D += D.T
+        MR, MRR, MDR, MAP, tops = evalstats.get_eval_statistics(D, corpus.cliques())
+        assert np.array_equal(np.array([MR, MRR, MDR, MAP] + list(tops)), want)
+    assert 0.6 <= float(g["stats_qmax"][3]) <= 0.9
 
 
 def test_reference_similarity_fixture(orc, golden):

@@ -95,3 +95,27 @@ def test_gather_scores_single_process():
     idx = np.array([4, 0, 2])
     out = sharding.gather_scores(torch.tensor([1.0, 2.0, 3.0]), idx, 6)
     assert out.tolist() == [2.0, 0.0, 3.0, 0.0, 1.0, 0.0]
+
+
+def _worker_forced(rank, world, port, K, tmp):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        truth = np.cos(np.arange(K)).astype(np.float64)
+        idx = np.arange(K)[::-1].copy()
+        for kw in ({"index_of_rank": lambda r: idx}, {}):
+            full = sharding.gather_scores(torch.from_numpy(truth[idx]), idx, K, force_collective=True, **kw)
+            assert np.array_equal(full.numpy(), truth)
+        np.save(os.path.join(tmp, "ok_forced.npy"), np.array([1]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_scores_forced_collective_in_a_one_rank_group(tmp_path):
+    """force_collective=True runs the all-gather in a world of one (the mode tests/test_gpu_rccl.py uses under "nccl");
+    without a process group it is an error, not a silent shortcut."""
+    mp.spawn(_worker_forced, args=(1, _free_port(), 37, str(tmp_path)), nprocs=1, join=True)
+    assert os.path.exists(os.path.join(str(tmp_path), "ok_forced.npy"))
+    with pytest.raises(RuntimeError):
+        sharding.gather_scores(torch.tensor([1.0]), np.array([0]), 1, force_collective=True)
