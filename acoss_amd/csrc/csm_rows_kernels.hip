@@ -38,6 +38,9 @@ constexpr int CR_RSRC_WORD3 = 0x00020000;
 #ifndef CR_WPS
 #define CR_WPS 4
 #endif
+#ifndef CR_PROBE
+#define CR_PROBE 0                   // development (tools/build_variant.py), wrong values, timing only: bit 0 = no square roots, bit 1 = no matrix
+#endif                               // instructions, bit 2 = no y loads inside the walk (the first step's operands again), bit 3 = no stores
 
 template <int D>
 __global__ __launch_bounds__(64 * CR_WAVES, D <= 12 ? CR_WPS : CR_WPS - 1) void csm_rows_kernel(const double *__restrict__ xp, int max_nx,
@@ -112,13 +115,19 @@ __global__ __launch_bounds__(64 * CR_WAVES, D <= 12 ? CR_WPS : CR_WPS - 1) void 
 #pragma unroll
             for (int u = 0; u < 2; u++) {
 #pragma unroll
-                for (int v = 0; v < 2; v++) acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], bcur[v][s], acc[u][v], 0, 0, 0);
+                for (int v = 0; v < 2; v++) {
+                    if (CR_PROBE & 2) acc[u][v][s & 3] += a[u][s] + bcur[v][s];
+                    else acc[u][v] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[u][s], bcur[v][s], acc[u][v], 0, 0, 0);
+                }
             }
         }
-        if (t + 1 < n_steps) load_y(t + 1, bcur, ynext);
+        if (!(CR_PROBE & 4) && t + 1 < n_steps) load_y(t + 1, bcur, ynext);
         // epilogue in the accumulator layout: cv[u][r][v] = cell (row 16 u + 4 r + lk, column c0 + v)
+        // (the test for values the fast square root cannot take runs on the HIGH WORDS, full-rate integer minima instead of
+        // two float64 compares per value: a value >= +0 lies below 2^-900 iff its high word is below 0x07B00000 -- which
+        // sends exact zeros to the general form too, where they take the same iteration as here)
         double cv[2][4][2];
-        bool tiny = false;
+        unsigned min_hi = 0xFFFFFFFFu;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
 #pragma unroll
@@ -126,16 +135,17 @@ __global__ __launch_bounds__(64 * CR_WAVES, D <= 12 ? CR_WPS : CR_WPS - 1) void 
 #pragma unroll
                 for (int v = 0; v < 2; v++) {
                     cv[u][r][v] = fmax(fma(-2.0, acc[u][v][r], xn[u][r] + ycur[v]), 0.0);
-                    tiny |= csm_sqrt_is_tiny(cv[u][r][v]);
+                    min_hi = min(min_hi, (unsigned)__double2hiint(cv[u][r][v]));
                 }
             }
         }
+        const bool tiny = min_hi < 0x07B00000u;
         // stores: four rows x 256 contiguous bytes per wave instruction.  Rows past the end of the song fall outside the
         // buffer resource (the hardware drops them); a piece that reaches past the last column, or a pair whose matrix
         // does not start on a 16-byte boundary, takes the checked 8-byte form.
         const bool whole = even_layout && (t * CR_WAVES + wave + 1) * CR_CW <= ds.ny;        // wave-uniform
-        // COMMON = the piece lies inside the row, 16-byte stores, no value below 2^-900 (one wave-uniform test: never taken
-        // on real features, see csm_sqrt); the other form checks every store and scales tiny values before the iteration
+        // COMMON = the piece lies inside the row, 16-byte stores, every value >= 2^-900 (one wave-uniform test; exact zeros --
+        // identical frames -- and values the iteration cannot take go the other way); the other form checks every store and scales tiny values before the iteration
         auto finish = [&](auto common_tag) {
             constexpr bool COMMON = decltype(common_tag)::value;
 #pragma unroll
@@ -146,8 +156,9 @@ __global__ __launch_bounds__(64 * CR_WAVES, D <= 12 ? CR_WPS : CR_WPS - 1) void 
 #pragma unroll
                     for (int v = 0; v < 2; v++) {
                         c[v] = cv[u][r][v];
-                        if (COMMON) {
-                            c[v] = csm_sqrt_fast(c[v]);
+                        if (CR_PROBE & 1) {
+                        } else if (COMMON) {
+                            c[v] = csm_sqrt_fast<true>(c[v]);
                         } else {
                             // below 2^-900 the iteration's intermediates leave the normal range: take the root of c 2^200 (exact
                             // scaling by an even power of two) and scale back -- what a correctly rounded sqrt returns
@@ -158,7 +169,9 @@ __global__ __launch_bounds__(64 * CR_WAVES, D <= 12 ? CR_WPS : CR_WPS - 1) void 
                     const int soff = cell_off + 8 * ((16 * u + 4 * r) * ds.csm_pitch);   // per lane (row 16 u + 4 r + lk): a vector offset
                     const u32x2r w0 = {(unsigned)__double2loint(c[0]), (unsigned)__double2hiint(c[0])};
                     const u32x2r w1 = {(unsigned)__double2loint(c[1]), (unsigned)__double2hiint(c[1])};
-                    if (COMMON) {
+                    if (CR_PROBE & 8) {
+                        if (c[0] == -1.25) __builtin_amdgcn_raw_buffer_store_b64(w1, orsrc, soff, 0, CR_STORE_POLICY);
+                    } else if (COMMON) {
                         __builtin_amdgcn_raw_buffer_store_b128((u32x4r){w0.x, w0.y, w1.x, w1.y}, orsrc, soff, 0, CR_STORE_POLICY);
                         // (left alone the scheduler interleaves all sixteen root iterations and spills)
                         __builtin_amdgcn_sched_barrier(0);

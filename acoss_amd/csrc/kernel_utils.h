@@ -58,9 +58,11 @@ __device__ inline float csm_sqrt(float c) { return sqrtf(fmaxf(c, 0.0f)); }
 // The two halves of csm_sqrt(double) for kernels that take many roots at once: one wave-uniform test over all of a lane's
 // values, then the branch-free iteration (c >= 0, not in (0, 2^-900)) -- the same instructions, the same bits.
 __device__ inline bool csm_sqrt_is_tiny(double c) { return c > 0.0 && c < 0x1.0p-900; }
+template <bool NONZERO = false>
 __device__ inline double csm_sqrt_fast(double c)
 {
-    const double y = __builtin_amdgcn_rsq(fmax(c, 0x1.0p-900));
+    // (NONZERO: the caller has established c >= 2^-900, the seed needs no guard against 1 / sqrt(0))
+    const double y = __builtin_amdgcn_rsq(NONZERO ? c : fmax(c, 0x1.0p-900));
     double g = c * y, h = 0.5 * y;
     const double r = fma(-h, g, 0.5);
     g = fma(g, r, g);

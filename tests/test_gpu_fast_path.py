@@ -65,7 +65,8 @@ def test_row_band_csm_equals_the_valu_kernel_on_ragged_batches(eng, d):
     feats = rng.random((sum(lens), d))
     off = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     corpus = eng.DeviceCorpus(feats, off, gchroma=rng.random((len(lens), 12)) if d == 12 else None)
-    pairs = [(i, j) for i in range(len(lens)) for j in (0, 3, 7, 11, 15, 16) if i != j][:64]
+    pairs = [(i, j) for i in range(len(lens)) for j in (0, 3, 7, 11, 15, 16) if i != j][:60] + [(5, 5), (12, 12), (15, 15), (16, 16)]
+    # (self pairs: exact zeros on the diagonal -- the values the kernel's fast square root must not be given)
     for pitch_align in (16, 32):
         batch = eng.PairBatch(corpus.frame_off, pairs, 1, corpus.device, pitch_align=pitch_align)
         if d == 12:
@@ -83,6 +84,8 @@ def test_row_band_csm_equals_the_valu_kernel_on_ragged_batches(eng, d):
             G = gh[o:o + nx * pt].reshape(nx, pt)
             W = wh[o:o + nx * pt].reshape(nx, pt)
             assert np.array_equal(G[:, :ny], W[:, :ny]), (p, nx, ny)
+            if pairs[p][0] == pairs[p][1] and d == 13:
+                assert np.all(np.diag(G[:, :ny]) == 0.0)
             untouched[o:o + nx * pt].reshape(nx, pt)[:, :ny] = False
         assert np.all(gh[untouched] == fill)
 
