@@ -51,6 +51,7 @@ class Serra09(CoverAlgorithm):
         Cached features
     """
     KEYS = ["ssms_scatter_qmax", "ssms_scatter_dmax", "chroma_qmax", "chroma_dmax", "mfcc_qmax", "mfcc_dmax"]
+    alignments = ("qmax", "dmax")          # (subclasses that keep the reference's constructor: the reference's pair)
 
     def __init__(self, datapath="../features_covers80", chroma_type='crema', shortname='benchmark',
                  oti=True, kappa=0.095, m=9, downsample_fac=40, do_memmaps=True, cachedir="cache",

@@ -890,8 +890,6 @@ int acoss_mask_bits_fused_batch(const float *pk, const float *band, const double
     // enough that a batch still has thousands of blocks (small batches get shorter runs)
     const int bands_m = ceil_div(max_m, BD_R), bands_n = ceil_div(max_n, BD_R);
     int run_bands = 14;
-    const char *rb = getenv("ACOSS_BAND_RUN");
-    if (rb && atoi(rb) > 0) run_bands = atoi(rb);
     while (run_bands > 1 && (int64_t)K * (ceil_div(bands_m, run_bands) + (mutual ? ceil_div(bands_n, run_bands) : 0)) < 4096) run_bands = (run_bands + 1) / 2;
     const int runs_m = ceil_div(bands_m, run_bands), runs_n = mutual ? ceil_div(bands_n, run_bands) : 0;
     const int64_t blocks = (int64_t)K * (runs_m + runs_n);

@@ -661,6 +661,9 @@ __global__ __launch_bounds__(256, CPL == 16 ? 4 : 2) void dp_bits_kernel(const u
 // row pipeline as dp_bits_kernel<KIND_QMAX, 16>.
 // ---------------------------------------------------------------------------------------------
 typedef unsigned short dp_u16x2 __attribute__((ext_vector_type(2)));
+#ifndef DP_QD16_DEFAULT
+#define DP_QD16_DEFAULT 1             // acoss_align_bits_qd_batch: 1 = the one-sweep 16-bit kernel (round 4), 0 = the two 16-bit kernels
+#endif
 
 __global__ __launch_bounds__(256, 6) void dp_bits_q16_kernel(const uint64_t *__restrict__ bits,
                                                               const acoss_pair_desc *__restrict__ descs, int K, int win,
@@ -861,6 +864,170 @@ __global__ __launch_bounds__(256, 4) void dp_bits_d16_kernel(const uint64_t *__r
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) b = max(b, (unsigned)__shfl_xor((int)b, off));
     if (lane == 0) scores[p] = 0.5f * (float)b;
+}
+
+// qmax AND dmax in 16-bit integers in ONE sweep over the mask (round 4): what Serra09.similarity asks for per mask
+// (Serra09.py:173-175; `boundary` = dmax on the D that qmax leaves behind).  The two recurrences of dp_bits_q16_kernel and
+// dp_bits_d16_kernel are independent given the mask rows, so their dependent chains interleave in one instruction stream: the
+// mask row, its table look-ups and the loop are shared, and a wave always has a second chain to issue from.  Three changes
+// against the separate dmax kernel: the mask values (2 per set bit) come from a second table instead of an AND per register;
+// the (i-3, j-1) predecessor is carried -- c4(i) = D[i-3][j-1] + S[i-2][j] + S[i-1][j] = c2(i-1) + S[i-1][j], where c2(i-1) is
+// the previous row's (i-2, j-1) term -- so neither the row i-3 nor the mask values of row i-2 are kept.  Scores identical by construction
+// (integers).
+__global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__restrict__ bits,
+                                                               const acoss_pair_desc *__restrict__ descs, int K, int win,
+                                                               int max_m, int boundary, float *__restrict__ qscores,
+                                                               float *__restrict__ dscores)
+{
+    __shared__ __attribute__((aligned(16))) uint4 lut3[256], lut2[256];
+    {
+        // entry b: register r (cells 2r, 2r+1 of a byte's eight) -> 3 (lut3) / 2 (lut2) in the half of every set bit
+        const unsigned b = threadIdx.x;
+        unsigned e[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) e[r] = (((b >> (2 * r)) & 1u) ? 1u : 0u) | (((b >> (2 * r + 1)) & 1u) ? 0x10000u : 0u);
+        lut3[b] = make_uint4(3u * e[0], 3u * e[1], 3u * e[2], 3u * e[3]);
+        lut2[b] = make_uint4(2u * e[0], 2u * e[1], 2u * e[2], 2u * e[3]);
+    }
+    __syncthreads();
+    constexpr int PF = 6;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int p = blockIdx.x * 4 + wave;
+    if (p >= K) return;
+    const int lane = threadIdx.x & 63;
+    const acoss_pair_desc ds = descs[p];
+    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
+    if (M < 3 || N < 3) {                        // SequenceAlignment.c:117-119 (and :151-153)
+        if (lane == 0) { qscores[p] = 0.0f; dscores[p] = 0.0f; }
+        return;
+    }
+    const bool with_d = M >= 4 && N >= 4;        // SequenceAlignment.c:151-153: dmax of a smaller matrix is 0 (wave-uniform)
+    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    auto pk = [](unsigned v) { return __builtin_bit_cast(dp_u16x2, v); };
+    auto un = [](dp_u16x2 v) { return __builtin_bit_cast(unsigned, v); };
+    const dp_u16x2 one = (dp_u16x2){1, 1};
+    const bool l0 = lane == 0;
+    // qmax state: row i-1; rows i-1 and i-2 shifted right by one cell
+    unsigned q1[8], q1s[8], q2s[8], qbest = 0u;
+    // dmax state: row i-1; rows i-1 and i-2 shifted right by one cell; the previous row's (i-2, j-1) term; mask values of row i-1
+    unsigned d1[8], d1s[8], d2s[8], c2p[8], a1[8], dbest = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; k++) q1[k] = q1s[k] = q2s[k] = d1[k] = d1s[k] = d2s[k] = c2p[k] = a1[k] = 0u;
+    auto unpack = [](const uint4 a, const uint4 b, unsigned (&o)[8]) {
+        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    };
+    // one row of qmax (dp_bits_q16_kernel's)
+    auto q_row = [&](const unsigned (&m3)[8]) {
+        const unsigned halo = (unsigned)lane_shr1((int)q1[7], 0);
+        unsigned nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned left2 = k >= 1 ? q1[k - 1] : halo;
+            const dp_u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(pk(q1s[k]), pk(q2s[k])), pk(left2));
+            unsigned v = un(__builtin_elementwise_sub_sat(m + pk(m3[k]), one));
+            if (k == 0) v = l0 ? 0u : v;
+            qbest = un(__builtin_elementwise_max(pk(qbest), pk(v)));
+            nd[k] = v;
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) q2s[k] = q1s[k];
+#pragma unroll
+        for (int k = 7; k >= 1; k--) q1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        q1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) q1[k] = nd[k];
+    };
+    // one row of dmax (dp_bits_d16_kernel's, with the carried (i-3, j-1) term)
+    auto d_row = [&](const unsigned (&m3)[8], const unsigned (&a0)[8]) {
+        const unsigned a0_prev = (unsigned)lane_shr1((int)a0[7], 0);
+        const unsigned d1_prev = (unsigned)lane_shr1((int)d1[7], 0);
+        const unsigned d1s_prev = (unsigned)lane_shr1((int)d1s[7], 0);
+        unsigned nd[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned a0m1 = k >= 1 ? a0[k - 1] : a0_prev;                    // S[i][j-2] (x 2)
+            const dp_u16x2 sl1 = pk(__builtin_amdgcn_alignbit(a0[k], a0m1, 16));   // S[i][j-1]
+            const dp_u16x2 su1 = pk(a1[k]);                                          // S[i-1][j]
+            const dp_u16x2 c1 = pk(d1s[k]);                                          // (i-1, j-1)
+            const dp_u16x2 c2 = pk(d2s[k]) + su1;                                    // (i-2, j-1) + S[i-1][j]
+            const dp_u16x2 c3 = pk(k >= 1 ? d1[k - 1] : d1_prev) + sl1;              // (i-1, j-2) + S[i][j-1]
+            const dp_u16x2 c4 = pk(c2p[k]) + su1;                                    // (i-3, j-1) + S[i-2][j] + S[i-1][j]
+            const dp_u16x2 c5 = pk(k >= 1 ? d1s[k - 1] : d1s_prev) + (pk(a0m1) + sl1);      // (i-1, j-3) + S[i][j-2] + S[i][j-1]
+            const dp_u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(__builtin_elementwise_max(c1, c2), __builtin_elementwise_max(c3, c4)), c5);
+            unsigned v = un(__builtin_elementwise_sub_sat(m + pk(m3[k]), one));
+            unsigned vb = v;                     // what counts for the maximum: columns >= 3
+            if (k == 0) { v = l0 ? 0u : v; vb = v; }
+            if (k == 1) {
+                vb = l0 ? (v & 0xFFFF0000u) : v;
+                v = l0 ? ((v & 0xFFFF0000u) | (boundary ? (a0[1] & 0xFFFFu) : 0u)) : v;       // column 2 = S[i][2] with the boundary
+            }
+            dbest = un(__builtin_elementwise_max(pk(dbest), pk(vb)));
+            nd[k] = v;
+            c2p[k] = un(c2);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { d2s[k] = d1s[k]; a1[k] = a0[k]; }
+#pragma unroll
+        for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        d1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+#pragma unroll
+        for (int k = 0; k < 8; k++) d1[k] = nd[k];
+    };
+    // rows 1 and 2: dmax only takes their mask values (c2p = 0 + S[1][j]: the carried term of row 3; with the boundary row 2 of D
+    // holds its mask values in columns >= 2); qmax computes row 2
+    {
+        const unsigned r1 = rowp[(int64_t)1 * 64], r2 = rowp[(int64_t)2 * 64];
+        unsigned m3[8];
+        unpack(lut2[r1 & 0xFFu], lut2[(r1 >> 8) & 0xFFu], c2p);
+        unpack(lut2[r2 & 0xFFu], lut2[(r2 >> 8) & 0xFFu], a1);
+        unpack(lut3[r2 & 0xFFu], lut3[(r2 >> 8) & 0xFFu], m3);
+        if (boundary) {
+#pragma unroll
+            for (int k = 0; k < 8; k++) d1[k] = a1[k];
+            if (l0) d1[0] = 0u;
+#pragma unroll
+            for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(d1[k], d1[k - 1], 16);
+            d1s[0] = __builtin_amdgcn_alignbit(d1[0], (unsigned)lane_shr1((int)d1[7], 0), 16);
+        }
+        q_row(m3);
+    }
+    int i = 3;
+    if (with_d) {
+        unsigned ring[PF];
+#pragma unroll
+        for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+        for (; i + PF <= M; i += PF) {
+#pragma unroll
+            for (int u = 0; u < PF; u++) {
+                const unsigned m0 = ring[u];
+                ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
+                unsigned m3[8], a0[8];
+                unpack(lut3[m0 & 0xFFu], lut3[(m0 >> 8) & 0xFFu], m3);
+                unpack(lut2[m0 & 0xFFu], lut2[(m0 >> 8) & 0xFFu], a0);
+                q_row(m3);
+                d_row(m3, a0);
+            }
+        }
+    }
+#pragma unroll 1
+    for (; i < M; i++) {
+        const unsigned m0 = rowp[(int64_t)i * 64];
+        unsigned m3[8], a0[8];
+        unpack(lut3[m0 & 0xFFu], lut3[(m0 >> 8) & 0xFFu], m3);
+        unpack(lut2[m0 & 0xFFu], lut2[(m0 >> 8) & 0xFFu], a0);
+        q_row(m3);
+        if (with_d) d_row(m3, a0);
+    }
+    unsigned bq = max(qbest & 0xFFFFu, qbest >> 16), bd = max(dbest & 0xFFFFu, dbest >> 16);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        bq = max(bq, (unsigned)__shfl_xor((int)bq, off));
+        bd = max(bd, (unsigned)__shfl_xor((int)bd, off));
+    }
+    if (lane == 0) {
+        qscores[p] = 0.5f * (float)bq;
+        dscores[p] = with_d ? 0.5f * (float)bd : 0.0f;
+    }
 }
 
 // qmax and dmax of the same mask in ONE sweep (what Serra09.similarity asks for, Serra09.py:173-175: dmax on the D
@@ -1100,6 +1267,13 @@ int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs
     // 12 unconditional rows), qmax and dmax as two launches (0.69 + 1.24 ms per 4096 pairs of 1000-frame songs) beat the
     // one-sweep kernel (2.02 ms: 230 registers, two waves per SIMD).  ACOSS_DP_ONE_SWEEP=1 keeps the old form.
     static const bool one_sweep = []() { const char *e = getenv("ACOSS_DP_ONE_SWEEP"); return e && e[0] == '1'; }();
+    static const bool q16 = []() { const char *e = getenv("ACOSS_DP_Q16"); return !(e && e[0] == '0'); }();
+    if (DP_QD16_DEFAULT && !one_sweep && q16 && ap.gamma_onset == 0.5f && mask_bits_words(max_m, max_n) == 16) {
+        // round 4: both recurrences in 16-bit integers in one sweep (dp_bits_qd16_kernel)
+        hipLaunchKernelGGL(dp_bits_qd16_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m, boundary,
+                           qmax_scores, dmax_scores);
+        return launch_check("dp_bits_qd16_kernel");
+    }
     if (!one_sweep) {
         int rc = acoss_align_bits_batch(0, bits, descs, K, win, max_nx, max_ny, 0, params, qmax_scores, stream);
         if (rc == ACOSS_OK) rc = acoss_align_bits_batch(1, bits, descs, K, win, max_nx, max_ny, boundary, params, dmax_scores, stream);

@@ -402,7 +402,7 @@ static int run_planar(int probe, const uint32_t *planes, const double *feats, co
     }
     ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
     w.band = band;
-    if (band == nullptr || probe != 0 || getenv("ACOSS_NO_SIDE_FIX")) {       // exact keys: nothing is handed over
+    if (band == nullptr || probe != 0) {       // exact keys: nothing is handed over
         w.side_counter = nullptr;
         w.side_slots = nullptr;
         w.side_keys = nullptr;

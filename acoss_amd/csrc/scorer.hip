@@ -23,8 +23,8 @@ struct acoss_corpus {
     int n_songs = 0, d = 0, nbins = 0;
     int64_t n_frames = 0;
     bool owns = false, f32_ok = false;
-    bool force_f64 = false;                     // ACOSS_SCORER_F64, read once when the handle is made
-    bool keys16 = true;                         // ACOSS_SCORER_KEYS16=0: 32-bit keys for the float32 filter (round 2's form)
+    bool force_f64 = false;                     // ACOSS_PLANAR32=0, read once when the handle is made
+    bool keys16 = true;                         // ACOSS_KEYS16=0: 32-bit keys for the float32 filter (round 2's form)
     std::mutex call_mutex;                      // the staging below belongs to one acoss_serra09_scores call at a time
     std::vector<int64_t> frame_off;
     std::vector<double> norms_scaled;           // squared norms of the centred, scaled frames (float64, host)
@@ -202,9 +202,10 @@ int acoss_corpus_wrap(const double *feats, const double *norms, const double *gc
     c->f32 = const_cast<float *>(f32);
     c->n32 = const_cast<float *>(n32);
     c->f32_ok = f32 && n32 && norms_scaled;
-    const char *env = getenv("ACOSS_SCORER_F64");
-    c->force_f64 = env && env[0] && strcmp(env, "0") != 0;
-    const char *e16 = getenv("ACOSS_SCORER_KEYS16");
+    // the two switches of the product chain (README.md, "Switches"), read once, when the handle is made
+    const char *env = getenv("ACOSS_PLANAR32");
+    c->force_f64 = env && strcmp(env, "0") == 0;
+    const char *e16 = getenv("ACOSS_KEYS16");
     c->keys16 = !(e16 && strcmp(e16, "0") == 0);
     if (c->f32_ok) c->norms_scaled.assign(norms_scaled, norms_scaled + c->n_frames);
     *out = c;

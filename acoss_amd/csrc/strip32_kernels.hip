@@ -1,21 +1,19 @@
-// strip32_kernels.hip -- the fused CSM + sliding-window strip kernel (fused_kernels.hip: crp_strip_kernel) in float32.
+// strip32_kernels.hip -- cross-similarity + sliding window in float32: the FILTER in front of the kNN selection
+// (CRPUtils.py:67-84 + :24-45 fused; crp_rows32_kernel, the dominant kernel of the product path).
 //
-// Why: the float64 strip kernel is bound by float64 instruction issue (v_mfma_f64 and the float64 VALU share a rate of
-// 128 flop / clk / CU on gfx950 and do not overlap).  The masks only need the windowed sums T exactly where they are
-// compared against a row's / column's k-th smallest value; everywhere else an approximation with a known error bound
-// decides the same way.  This kernel produces that approximation: T~ in float32 (v_mfma_f32_16x16x4_f32 at twice the
-// float64 rate, the window sums as packed float32 adds at four times the rate), written as the uint32 matrix the
-// selection kernels of planar_kernels.hip read (order-preserving keys: the bit pattern of a float32 >= +0 with the sign
-// bit set).  Rows and columns in which another value lies within the error band of the k-th smallest are finished in
-// float64 by the fix-up kernel (planar_kernels.hip), so the masks equal those of the float64 path bit for bit.
+// Why float32: the masks need the windowed sums T exactly only where they are compared against a row's / column's k-th
+// smallest value; everywhere else an approximation with a known error bound decides the same way.  This kernel produces that
+// approximation -- T~ on v_mfma_f32_16x16x4_f32 (a k-ordered chain of round-to-nearest FMAs: pinned by
+// tests/test_gpu_fast_path.py against a host emulation) with the window sums as packed float32 adds -- and writes it either
+// as 16-bit keys (keys16.h: the product path, 2 bytes per cell) or as order-preserving uint32 keys (4 bytes per cell: the
+// bit pattern of a float32 >= +0 with the sign bit set).  Rows and columns in which another value lies within the error
+// band of the k-th smallest are finished in float64 by the refinement kernels, so the masks equal the float64 path's bit for bit.
 //
-// Error bound used by the callers: |T~ - T| <= 2^-24 * (16.5 * sum_k (|x_{i+k}|^2 + |y_{j+k}|^2) + 9.5 T) for the
-// operands it is given (the host passes the corpus with its mean subtracted: same distances, a third of the norms).
+// Error bound used by the callers: |T~ - T| <= 2^-24 * ((d + 4.5) * sum_k (|x_{i+k}|^2 + |y_{j+k}|^2) + 9.5 T)
+// for the operands it is given (the host passes the corpus with its mean subtracted: same distances, a third of the norms).
 //
-// Same decomposition as the float64 kernel: a persistent 8-wave block per 120-column strip of a pair walks down in
-// 32-row steps; C rows on the matrix cores into LDS, window sums by diagonal runs (a lane walks two adjacent
-// diagonals for 4 rows: 12 aligned 8-byte LDS reads, every output = window_sum9() of kernel_utils.h), one 8-byte store per
-// lane and row through a raw buffer resource.
+// (Round 2's column-strip form of this kernel -- a block per 112-column strip walking down, 448-byte row pieces -- was removed
+// in round 4: it cannot write 2-byte cells efficiently and its 4-byte form depended on the placement of the output buffer.)
 #include "common.h"
 #include "kernel_utils.h"
 
@@ -28,169 +26,22 @@ typedef float v4f32 __attribute__((ext_vector_type(4)));
 typedef float v2f32 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x2s_t __attribute__((ext_vector_type(2)));
 
-constexpr int S32_ROWS = 32;            // C rows per step
 constexpr int S32_WIN = 9, S32_HALO = S32_WIN - 1;
-constexpr int S32_TN = 112;             // output columns per strip (<= 128 C columns - S32_HALO): 448-byte row pieces, every one
-                                        // 64-byte aligned when the pitch is; 120-column pieces (half of them 32 bytes off) store 27 % slower
-constexpr int S32_LD = 131;             // odd: the two-element diagonal reads (row stride LD + 1) stay 8-byte aligned
-constexpr int S32_XLD = 17;             // packed x line: 16 floats
-constexpr int S32_XP = 16;
-constexpr int S32_RPW = S32_ROWS / 8;   // output rows per wave and step
+constexpr int S32_XP = 16;              // packed x line: 16 floats (d bins, the squared norm, zeros)
 constexpr int S32_CPAD = 8;
 constexpr int S32_RSRC_WORD3 = 0x00020000;
 
-// MODE (development probe): 1 = no result stores
 // cache policy of the key stores (raw buffer store aux bits on gfx950: 1 = sc0, 2 = nt, 16 = sc1): the matrix is written
 // once and read back from HBM long after it has left every cache
 #ifndef S32_STORE_POLICY
 #define S32_STORE_POLICY 2
 #endif
 
-template <int D, int MODE = 0>
-__global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restrict__ xp, int max_nx,
-                                                          const float *__restrict__ feats, const float *__restrict__ norms,
-                                                          const acoss_pair_desc *__restrict__ descs, int strips,
-                                                          uint32_t *__restrict__ out)
-{
-    constexpr int CROWS = S32_ROWS + S32_HALO;
-    constexpr int KSTEPS = (D + 3) / 4;
-    __shared__ __attribute__((aligned(16))) float cbuf_raw[CROWS * S32_LD + 2 * S32_CPAD + 1];
-    __shared__ __attribute__((aligned(16))) float xs[S32_ROWS * S32_XLD];
-    float *const cbuf = cbuf_raw + S32_CPAD;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int p = lb / strips;
-    const acoss_pair_desc ds = descs[p];
-    const int M = ds.nx - S32_WIN + 1, N = ds.ny - S32_WIN + 1;
-    const int j0 = (lb % strips) * S32_TN;
-    if (j0 >= N) return;
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, lk = lane >> 4;
-    const int n_steps = (ds.nx + S32_ROWS - 1) / S32_ROWS;
-    const float *xsrc = xp + (int64_t)p * max_nx * S32_XP;
-    const int last_chunk = ds.nx * (S32_XP / 4) - 1;            // 16-byte chunks of valid frames
-
-    // y fragments of this wave's 16 columns (kept for the whole strip)
-    float bfrag[KSTEPS], yy;
-    {
-        const int jc = min(j0 + 16 * wave + lr, ds.ny - 1);
-        const float *yp = feats + (ds.y_row0 + jc) * D;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; s++) {
-            const int bin = 4 * s + lk;
-            bfrag[s] = bin < D ? yp[min(bin, D - 1)] : 0.0f;
-        }
-        yy = norms[ds.y_row0 + jc];
-    }
-    // x frames: 32 frames x 64 bytes per step = 128 chunks of 16 bytes
-    const bool loader = tid < S32_ROWS * (S32_XP / 4);
-    float *xs_dst = &xs[(tid >> 2) * S32_XLD + (tid & 3) * 4];
-    auto put_x = [&](const float4 v) { xs_dst[0] = v.x; xs_dst[1] = v.y; xs_dst[2] = v.z; xs_dst[3] = v.w; };
-    if (loader) put_x(reinterpret_cast<const float4 *>(xsrc)[min(tid, last_chunk)]);
-    __syncthreads();
-
-    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(out) + 4 * ds.crp_off, 0, (int)(4 * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
-    if ((int64_t)4 * ((int64_t)M + 2 * S32_ROWS) * ds.crp_pitch > 0x7fffffffLL) return;      // 32-bit offsets, see strip_offsets_fit()
-    const int orow0 = (wave * S32_RPW - S32_HALO) * ds.crp_pitch + j0;
-
-    float4 xn1 = make_float4(0.f, 0.f, 0.f, 0.f), xn2 = xn1;
-    if (loader && n_steps > 1) xn1 = reinterpret_cast<const float4 *>(xsrc)[min(S32_ROWS * (S32_XP / 4) + tid, last_chunk)];
-
-    float *const wr = cbuf + (S32_HALO + 4 * lk) * S32_LD + 16 * wave + lr;
-    const int dcol = 2 * lane - S32_RPW;
-    const float *const rdd = cbuf + (wave * S32_RPW) * S32_LD + dcol;
-    // halo copy: rows [32, 40) -> [0, 8): 1024 floats, two per thread
-    const int hrow = tid >> 6, hcol = 2 * (tid & 63);
-    float *const halo_src = cbuf + (S32_ROWS + hrow) * S32_LD + hcol;
-    float *const halo_dst = cbuf + hrow * S32_LD + hcol;
-
-    auto step = [&](const int t, auto checked_tag) {
-        constexpr bool CHECKED = decltype(checked_tag)::value;
-        const bool more = t + 1 < n_steps;
-        if (loader && t + 2 < n_steps)
-            xn2 = reinterpret_cast<const float4 *>(xsrc)[min((t + 2) * S32_ROWS * (S32_XP / 4) + tid, last_chunk)];
-        // ---- C rows [32t, 32t+32) of this wave's 16 columns -> cbuf rows [HALO, HALO+32)
-        {
-            float nsum[2][4];
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++) nsum[rb][r] = xs[(16 * rb + 4 * lk + r) * S32_XLD + D];
-            }
-            v4f32 acc[2];
-            acc[0] = (v4f32){0.f, 0.f, 0.f, 0.f};
-            acc[1] = (v4f32){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-            for (int s = 0; s < KSTEPS; s++) {
-#pragma unroll
-                for (int rb = 0; rb < 2; rb++) {
-                    const float a = xs[(16 * rb + lr) * S32_XLD + 4 * s + lk];
-                    acc[rb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bfrag[s], acc[rb], 0, 0, 0);
-                }
-            }
-#pragma unroll
-            for (int rb = 0; rb < 2; rb++) {
-#pragma unroll
-                for (int r = 0; r < 4; r++)
-                    wr[(16 * rb + r) * S32_LD] = fmaxf(fmaf(-2.0f, acc[rb][r], nsum[rb][r] + yy), 0.0f);
-            }
-        }
-        lds_barrier();
-        if (loader && more) put_x(xn1);
-        xn1 = xn2;
-        // ---- output rows [32t - HALO, 32t + 32 - HALO): S32_RPW per wave, window sums from LDS
-        const int g0 = t * S32_ROWS - S32_HALO + wave * S32_RPW;
-        v2f32 v[S32_RPW + S32_HALO];
-#pragma unroll
-        for (int m = 0; m < S32_RPW + S32_HALO; m++) v[m] = *reinterpret_cast<const v2f32 *>(rdd + m * (S32_LD + 1));
-#pragma unroll
-        for (int q = 0; q < S32_RPW; q++) {
-            const int gi = g0 + q;
-            const v2f32 s = window_sum9(&v[q], window_sum9_odd(gi));        // (wave-uniform branch)
-            const int col = dcol + q;
-            const int soff = 4 * (orow0 + (t * S32_ROWS + q) * ds.crp_pitch);
-            const uint32_t ha = __float_as_uint(s.x) | 0x80000000u, hb = __float_as_uint(s.y) | 0x80000000u;
-            if (MODE == 1) {
-                if (s.x == -1.25f) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, 4 * (col & 63), soff, 0);
-            } else if (CHECKED) {
-                const bool row_ok = gi >= 0 && gi < M;
-                if (row_ok && col >= 0 && col < S32_TN && j0 + col < N) __builtin_amdgcn_raw_buffer_store_b32(ha, orsrc, 4 * col, soff, S32_STORE_POLICY);
-                if (row_ok && col + 1 >= 0 && col + 1 < S32_TN && j0 + col + 1 < N) __builtin_amdgcn_raw_buffer_store_b32(hb, orsrc, 4 * (col + 1), soff, S32_STORE_POLICY);
-            } else {
-                uint32_t h0 = ha, h1 = hb;
-                int ps = col;
-                if ((q & 1) != 0) {
-                    h0 = hb;
-                    h1 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)ha, 0x130, 0xf, 0xf, true);   // wave_shl:1
-                    ps = col + 1;
-                }
-                if (ps >= 0 && ps < S32_TN) __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){h0, h1}, orsrc, 4 * ps, soff, S32_STORE_POLICY);
-            }
-        }
-        // carry the last HALO C rows over to the next step: read before the barrier, write after it
-        const float h0v = halo_src[0], h1v = halo_src[1];
-        lds_barrier();
-        halo_dst[0] = h0v;
-        halo_dst[1] = h1v;
-    };
-    const bool full_strip = (j0 + S32_TN <= N) && ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);   // block-uniform
-    step(0, std::true_type{});
-    if (full_strip) {
-        for (int t = 1; t < n_steps - 1; t++) step(t, std::false_type{});
-    } else {
-        for (int t = 1; t < n_steps - 1; t++) step(t, std::true_type{});
-    }
-    if (n_steps > 1) step(n_steps - 1, std::true_type{});
-}
-
-
 // ---------------------------------------------------------------------------------------------------------------------
-// The same computation turned by 90 degrees (round 3): x stationary, y streaming.  A block owns a BAND of 56 output rows
+// Row bands (round 3): x stationary, y streaming.  A block owns a BAND of 56 output rows
 // of one pair (64 C rows: the window's 8-row halo is recomputed per band, the same 14 % the column strips recompute) and
 // walks RIGHT over the columns in chunks of 128 C columns; the last 15 columns of a chunk are carried to the next one
-// inside LDS.  Why: the column-strip kernel stores 448-byte row pieces at a 4 KB pitch (5.1 TB/s as a pure store pattern,
+// inside LDS.  Why: a column-strip kernel stores 448-byte row pieces at a 4 KB pitch (5.1 TB/s as a pure store pattern,
 // tools/ubench/plane_layout.hip); here every wave instruction stores 512 contiguous, line-aligned bytes of ONE row and the
 // next chunk continues that row (5.8 TB/s), and -- what the column strips cannot do at all without halving their store
 // rate -- the same rows can leave as two 16-bit planes of 256-byte pieces (5.6 TB/s) for the selection kernels to read
@@ -199,8 +50,9 @@ __global__ __launch_bounds__(512) void crp_strip32_kernel(const float *__restric
 // Per chunk: C[64][128] on the matrix cores into LDS (wave w: columns 16w .. 16w+15, four 16-row tiles; the y fragments
 // of the next chunk are already in flight), LDS-only barrier, then wave w forms rows 7w .. 7w+6 of the band: a lane walks
 // two adjacent diagonals down 7 rows (15 single 8-byte LDS reads for 14 outputs); the seven window sums share their partial
-// sums (24 packed additions; window_sum9() of kernel_utils.h defines the association) -- the arithmetic of
-// crp_strip32_kernel cell for cell (tests/test_gpu_fast_path.py pins both against the host emulation).  Walking diagonals, the columns a lane holds drift by one per row, so row q of a chunk covers columns
+// sums (24 packed additions; window_sum9() of kernel_utils.h defines the association; tests/test_gpu_fast_path.py pins every
+// key against the host emulation of that chain).  Walking diagonals, the columns a lane holds drift by one per row, so row q
+// of a chunk covers columns
 // [A + q, A + q + 128) with A = 128 t - 15 (+ 1 in odd waves: 8-byte alignment of the diagonal reads).  Stores must be
 // line-aligned (the same pieces shifted by a few cells store at half the rate), so each row is brought into place in
 // registers: the aligned block [128 (t-1), 128 t) of a row is the tail of what the previous chunk produced (kept in two
@@ -216,7 +68,7 @@ constexpr int R32_RPW = R32_BR / 8;     // output rows per wave
 #define R32_WPS 6                       // waves per SIMD the register allocation aims at: three blocks per CU (42 KB of LDS each)
 #endif
 
-// OUT: 0 = uint32 keys (the matrix crp_strip32_kernel writes); 1 = the 16-bit key plane of keys16.h (2 bytes per cell, two
+// OUT: 0 = uint32 keys; 1 = the 16-bit key plane of keys16.h (2 bytes per cell, two
 // resolutions in one monotone map: see there; `out` is then a uint16 matrix with the same element indexing);
 // 2 = no stores (development probe)
 template <int D, int OUT = 0>
@@ -510,31 +362,13 @@ extern "C" int acoss_crp_planar32_batch(const float *xp, const float *feats, con
         return ACOSS_ENOTSUP;
     }
     if (K == 0) return ACOSS_OK;
-    // ACOSS_STRIP32_FORM=cols: the column-strip kernel of round 2 (A/B comparisons); default: row bands
-    const char *form_env = getenv("ACOSS_STRIP32_FORM");
-    const bool form_rows = !(form_env && form_env[0] == 'c');
-    if (form_rows) {
-        const int bands = ceil_div(max_nx - win + 1, R32_BR);
-        if ((int64_t)K * bands > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
-        const unsigned nb = (unsigned)((int64_t)K * bands);
-        hipStream_t st2 = (hipStream_t)stream;
-#ifdef ACOSS_PROBES
-        if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_rows32_kernel<12, 2>), dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr); return launch_check("crp_rows32_kernel probe"); }
-#endif
-        if (d == 12) hipLaunchKernelGGL(crp_rows32_kernel<12>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
-        else hipLaunchKernelGGL(crp_rows32_kernel<13>, dim3(nb), dim3(512), 0, st2, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
-        return launch_check("crp_rows32_kernel");
-    }
-    const int strips = ceil_div(max_ny - win + 1, S32_TN);
-    if ((int64_t)K * strips > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
-    const unsigned blocks = (unsigned)((int64_t)K * strips);
+    const int bands = ceil_div(max_nx - win + 1, R32_BR);
+    if ((int64_t)K * bands > 0x7fffffffLL || !strip_offsets_fit(max_nx, max_ny, 4)) { set_error("crp_planar32_batch: batch too large"); return ACOSS_ENOTSUP; }
+    const unsigned nb = (unsigned)((int64_t)K * bands);
     hipStream_t st = (hipStream_t)stream;
-#ifdef ACOSS_PROBES
-    if (getenv("ACOSS_STRIP32_NOSTORE")) { hipLaunchKernelGGL((crp_strip32_kernel<12, 1>), dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out); return launch_check("crp_strip32_kernel probe"); }
-#endif
-    if (d == 12) hipLaunchKernelGGL(crp_strip32_kernel<12>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
-    else hipLaunchKernelGGL(crp_strip32_kernel<13>, dim3(blocks), dim3(512), 0, st, xp, max_nx, feats, norms, descs, strips, out);
-    return launch_check("crp_strip32_kernel");
+    if (d == 12) hipLaunchKernelGGL(crp_rows32_kernel<12>, dim3(nb), dim3(512), 0, st, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
+    else hipLaunchKernelGGL(crp_rows32_kernel<13>, dim3(nb), dim3(512), 0, st, xp, max_nx, feats, norms, descs, bands, out, (const uint32_t *)nullptr);
+    return launch_check("crp_rows32_kernel");
 }
 
 extern "C" int acoss_crp_keys16_batch(const float *xp, const float *feats, const float *norms, int d, const acoss_pair_desc *descs,

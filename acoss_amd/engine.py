@@ -653,12 +653,11 @@ def _scratch(name, numel, dtype, device, zero=False):
     return buf[:numel]
 
 
-def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
-    """The scorer's device scratch (grow-only, shared by successive calls).  The kernels that write and read the big
-    intermediate run 5-10 % faster or slower depending on WHICH allocation it lives in (a property of
-    the allocation's physical backing, stable for its lifetime), so a new buffer of more than 4 GiB is chosen among
-    ACOSS_SCRATCH_TRIALS (default 2, as memory allows) candidates by timing one batch of the call at hand in each;
-    ACOSS_SCRATCH_ARENA_GB=<n> scans the windows of one n-GB arena instead."""
+def _scorer_scratch(need, device):
+    """The scorer's device scratch: ONE plain allocation, grow-only, shared by successive calls.  (Rounds 2-3 timed trial
+    batches in several candidate allocations here, because the column-strip form of the strip kernel ran 5-10 % faster or
+    slower depending on the allocation's physical backing; with the row-band strip kernel the spread is 0-3 % (DESIGN.md
+    appendix A) and the trials went.)"""
     key = ("scorer", str(device), torch.uint8)
     buf = _SCRATCH.get(key)
     if buf is not None and buf.numel() >= need:
@@ -666,59 +665,7 @@ def _scorer_scratch(lib, h, pairs, m, kappa, do_oti, bp, need, device):
     _SCRATCH.pop(key, None)
     buf = None
     torch.cuda.empty_cache()
-    size = int(need * 1.05) + 16
-    trials = max(1, int(os.environ.get("ACOSS_SCRATCH_TRIALS", "2")))
-    free_b = torch.cuda.mem_get_info(device)[0]
-    trials = max(1, min(trials, int(0.6 * free_b // max(size, 1))))
-    arena_gb = float(os.environ.get("ACOSS_SCRATCH_ARENA_GB", "0"))
-    arena_b = int(min(arena_gb * (1 << 30), 0.6 * free_b))
-    if size < (4 << 30) or (trials == 1 and arena_b < 2 * size):
-        buf = torch.empty(size, dtype=torch.uint8, device=device)
-    elif arena_b >= 2 * size:
-        # opt-in: windows of one large arena, 4 GiB apart (a dedicated GPU with memory to spare: what bench.py does)
-        arena = torch.empty(arena_b, dtype=torch.uint8, device=device)
-        sample = np.ascontiguousarray(pairs[:min(len(pairs), 4096)])
-        sink = np.zeros(len(sample))
-        best_t, best_off = float("inf"), 0
-        for off in range(0, arena_b - size + 1, 4 << 30):
-            c = arena[off: off + size]
-            t = float("inf")
-            for rep in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                check(lib.acoss_serra09_scores(h, sample.ctypes.data, len(sample), m, kappa, int(do_oti), 1, bp, _ptr(c), c.numel(),
-                                               sink.ctypes.data, None, None, _stream()), "serra09_scores (placement trial)")
-                e1.record()
-                torch.cuda.synchronize()
-                if rep:
-                    t = min(t, e0.elapsed_time(e1))
-            if t < best_t:
-                best_t, best_off = t, off
-        buf = arena[best_off: best_off + size]         # (the view keeps the arena alive)
-    else:
-        sample = np.ascontiguousarray(pairs[:min(len(pairs), 4096)])
-        sink = np.zeros(len(sample))
-        cands, times = [], []
-        for _ in range(trials):
-            try:
-                cands.append(torch.empty(size, dtype=torch.uint8, device=device))
-            except RuntimeError:
-                break
-        for c in cands:
-            best = float("inf")
-            for rep in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                check(lib.acoss_serra09_scores(h, sample.ctypes.data, len(sample), m, kappa, int(do_oti), 1, bp, _ptr(c), c.numel(),
-                                               sink.ctypes.data, None, None, _stream()), "serra09_scores (placement trial)")
-                e1.record()
-                torch.cuda.synchronize()
-                if rep:
-                    best = min(best, e0.elapsed_time(e1))
-            times.append(best)
-        buf = cands[int(np.argmin(times))]
-        del cands
-        torch.cuda.empty_cache()
+    buf = torch.empty(int(need * 1.05) + 16, dtype=torch.uint8, device=device)
     _SCRATCH[key] = buf
     return buf[:need]
 
@@ -731,7 +678,7 @@ def release_scratch():
 
 def keys16_default():
     """Whether the float32 filter's keys are 16 bits wide (csrc/keys16.h: the default since round 3) or 32 (round 2's form,
-    ACOSS_KEYS16=0 / ACOSS_SCORER_KEYS16=0 for the C scorer)."""
+    ACOSS_KEYS16=0: the C scorer reads the same name when a corpus handle is made)."""
     return os.environ.get("ACOSS_KEYS16", "1") not in ("0", "", "false", "no")
 
 
@@ -795,7 +742,7 @@ def serra09_scores(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax", "
         need = int(lib.acoss_serra09_scratch_bytes(h, pairs.ctypes.data, K, int(m), bp))
         if need == 0:
             raise AcossError("serra09_scores: %s" % _lib.last_error())
-        scratch = _scorer_scratch(lib, h, pairs, int(m), float(kappa), bool(do_oti), bp, need, corpus.device)
+        scratch = _scorer_scratch(need, corpus.device)
         mask = sum(b for k, b in (("qmax", 1), ("dmax", 2), ("swc", 4)) if k in want)
         ptr = lambda k: out[k].ctypes.data if k in out else None
         check(lib.acoss_serra09_scores(h, pairs.ctypes.data, K, int(m), float(kappa), int(bool(do_oti)), mask, bp,

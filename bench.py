@@ -21,8 +21,8 @@ Prints ONE JSON line on rank 0.  `roofline` describes the strip kernel of the ti
 sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region (`stage_ms` has every stage);
 `roofline_selection.rows` / `.cols` the two selection kernels that read its output, each launched alone where it runs in the
 chain.  Beside each live block: the same kernel's average in the committed rocprofv3 summary (`profiles_avg_launch_ms`,
-`profiles_frac`), when profiles/r03_profile_meta.json names this workload.  The key matrix lives in a plain allocation
-(`placement_scanned` = the same steps after a scan of arena windows; ACOSS_BENCH_ARENA_GB=<n> makes the scan the headline's).
+`profiles_frac`), when profiles/r04_profile_meta.json names this workload.  The key matrix lives in a plain allocation
+(ACOSS_BENCH_ARENA_GB=<n> scans the windows of an n-GB arena for the fastest one first: rounds 2-3's placement study, opt-in).
 Beside the headline (rank 0, one GPU; `--no-extras` skips them): `roofline_csm_*` = the stand-alone get_csm kernels;
 `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores and whether the GPU scores of the sampled pairs are
 identical (also on N > 1 lines); `keys32_path` / `f64_path` / `fused` = the same steps with 32-bit keys, with every windowed sum
@@ -142,12 +142,9 @@ class Runner(object):
             self.koffs = [engine.keys16_koff(corpus, b) for b in batches]
         if path == "fused":
             self.bands = [engine.planar32_band(corpus, b, fused=True) for b in batches]
-        # Placement: the kernels that write and read the key matrix run up to 10 % faster or slower depending on which physical
-        # memory it lives in.  Round 3 closed the question with one experiment (tools/vmm_probe.py,
-        # profiles/r03_vmm_placement_probe.txt): no allocation path (hipMalloc, torch's allocator, hipMemCreate in one chunk or
-        # in 1 GB / 2 MB chunks; the recommended granularity is 4 KB) yields the fast class deterministically, so the scan
-        # of arena windows is OFF by default -- the headline is what a plain allocation gives -- and ACOSS_BENCH_ARENA_GB=<n>
-        # turns it on (the `placement_scanned` block of the JSON line reports it beside the headline).
+        # Placement (opt-in, ACOSS_BENCH_ARENA_GB=<n>): rounds 2-3 found the column-strip kernels 5-10 % faster or slower depending
+        # on which physical memory the key matrix lives in and scanned arena windows for the best one; with the row-band strip
+        # kernel the spread is 0-3 %, the headline is what a plain allocation gives.
         self.placement_ms = None
         if arena_gb is None:
             arena_gb = float(os.environ.get("ACOSS_BENCH_ARENA_GB", "0"))
@@ -325,16 +322,25 @@ def time_kernel(fn, torch, reps=5):
     return float(np.median(ms[1:]))
 
 
+def profile_file(suffix):
+    """The newest committed profile artefact profiles/rNN_<suffix> (tools/collect_profiles.sh + tools/adopt_profiles.py)."""
+    for tag in ("r04", "r03"):
+        f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, suffix))
+        if os.path.exists(f):
+            return f
+    return os.path.join(ROOT, "profiles", "r04_%s" % suffix)
+
+
 def pmc_traffic(path, kernel_key, P, frames):
     """HBM bytes per launch of the path's dominant kernel from the committed PMC passes (profiles/README.md: WRITE_SIZE
     exact, FETCH_SIZE x 2 on gfx950) -- only quoted when the profile was taken on this very workload and path."""
-    for name in ("r03_pmc.json", "r02_%s_pmc.json" % path, "r01_final_pmc.json"):
+    for name in (os.path.basename(profile_file("pmc.json")),):
         f = os.path.join(ROOT, "profiles", name)
         if not os.path.exists(f) or frames != 1000:
             continue
         with open(f) as fh:
             doc = json.load(fh)
-        if name.startswith("r03") and doc.get("_path") != path:
+        if doc.get("_path") != path:
             continue
         c = doc.get(kernel_key)
         if c and "hbm_write_GB" in c and doc.get("_pairs_per_step") == P:
@@ -345,11 +351,11 @@ def pmc_traffic(path, kernel_key, P, frames):
 
 def attach_profile_averages(out, P, args):
     """Beside every live roofline block the average duration of the same kernel in the committed rocprofv3 --kernel-trace
-    --stats summary (profiles/r03_kernel_stats.csv, collected by tools/collect_profiles.sh with this file's own command) and
+    --stats summary (profiles/rNN_kernel_stats.csv, collected by tools/collect_profiles.sh with this file's own command) and
     the fraction that follows from it -- only when the profile was taken on this workload (pairs per step, frames, path)."""
     import csv
-    meta_f = os.path.join(ROOT, "profiles", "r03_profile_meta.json")
-    stats_f = os.path.join(ROOT, "profiles", "r03_kernel_stats.csv")
+    meta_f = profile_file("profile_meta.json")
+    stats_f = profile_file("kernel_stats.csv")
     if not (os.path.exists(meta_f) and os.path.exists(stats_f)):
         return
     with open(meta_f) as fh:
@@ -367,7 +373,7 @@ def attach_profile_averages(out, P, args):
                 return ms
         return None
     pmc = {}
-    pmc_f = os.path.join(ROOT, "profiles", "r03_pmc.json")
+    pmc_f = profile_file("pmc.json")
     if os.path.exists(pmc_f):
         with open(pmc_f) as fh:
             pmc = json.load(fh)
@@ -388,7 +394,7 @@ def attach_profile_averages(out, P, args):
         work = blk.get("bytes_per_launch") or blk.get("flops_per_launch")
         blk["profiles_avg_launch_ms"] = round(ms, 4)
         blk["profiles_frac"] = round(work / ms / 1e6 / blk["peak"], 4) if blk["unit"] == "GB/s" else None
-        blk["profiles_source"] = "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of `%s`)" % meta.get("command", "bench.py")
+        blk["profiles_source"] = "profiles/%s (rocprofv3 --kernel-trace --stats of `%s`)" % (os.path.basename(stats_f), meta.get("command", "bench.py"))
         # what the kernel is bound by when it is not HBM: the SIMDs' busy fractions from the committed counter passes (SQ counters
         # in quad-cycles, MI355X_MICROARCH.md; kernel cycles = GRBM_GUI_ACTIVE / 8 XCDs)
         c = pmc.get(key)
@@ -397,7 +403,7 @@ def attach_profile_averages(out, P, args):
             blk["simd_busy"] = {"valu": round(c["SQ_ACTIVE_INST_VALU"] * 4.0 / 1024.0 / cyc, 3),
                                 "mfma": round(c.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / 1024.0 / cyc, 3),
                                 "waves_per_simd_resident": round(c["SQ_WAVE_CYCLES"] * 4.0 / 1024.0 / cyc, 2),
-                                "source": "profiles/r03_pmc.json (rocprofv3 --pmc passes of the same command; fractions of the kernel's cycles on the 1024 SIMDs)"}
+                                "source": "profiles/%s (rocprofv3 --pmc passes of the same command; fractions of the kernel's cycles on the 1024 SIMDs)" % os.path.basename(pmc_f)}
 
 
 def config3_job(tmpdir, alignments=("qmax", "dmax", "swc")):
@@ -953,7 +959,7 @@ def main():
             form = "rows32_kernel<12,0>" if os.environ.get("ACOSS_STRIP32_FORM", "r")[0] != "c" else "strip32_kernel<12>"
             kname = ("crp_%s (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
                      "refinement in select_fix_side_kernel)" % form)
-            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip32_kernel<12, 0>"
+            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, ("crp_rows32_kernel<12, 0>" if form.startswith("rows") else "crp_strip32_kernel<12, 0>")
         elif args.path == "fast":
             kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
             kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip_kernel<12, 9, false, 0, false, true>"
@@ -1118,25 +1124,8 @@ def main():
     if extras:
         from oracle import oracle
         last = scores[args.warmup:].clone()
-        runner_had_no_scan = runner.placement_ms is None
         del runner, events
         engine.release_scratch()
-        # the headline's path once more with the key matrix placed by a scan of arena windows (what round 2's headline did)
-        if runner_had_no_scan and args.path in ("fast16", "fast32", "fast"):
-            try:
-                rs = Runner(corpus, batches, m, kappa, args.path, arena_gb=float(os.environ.get("ACOSS_BENCH_SCAN_GB", "160")))
-                el_s, s_s, st_s = timed_steps(rs, n_steps, args.warmup, P, dev, torch)
-                out["placement_scanned"] = {"value": round(args.steps * P / el_s, 1), "unit": "pair-scores/s", "ms_per_step": round(1e3 * el_s / args.steps, 3),
-                                            "stage_ms": st_s, "scan": rs.placement_ms,
-                                            "scores_identical_to_headline": bool(torch.equal(s_s[args.warmup:], last)),
-                                            "note": "the headline uses a plain allocation; this block scans 4 GiB-spaced windows of one arena for the "
-                                                    "fastest strip + selection time first (DESIGN.md section 4a: a property of physical memory no "
-                                                    "allocation path controls)"}
-                del rs, s_s
-            except SystemExit:
-                pass
-            _ARENA.clear()
-            engine.release_scratch()
         # the same steps through the other compositions of the chain: scores must equal the headline's on every pair
         for key, other in (("keys32_path", "fast32"), ("f64_path", "fast"), ("fused", "fused")):
             if other == args.path or pitch != 32:

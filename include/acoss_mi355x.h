@@ -423,8 +423,9 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
  * and its squared norms; norms_scaled: those norms in float64 on the HOST; all three NULL: float64 kernels only); the
  * caller keeps ownership.  Thread safety: acoss_serra09_scores calls on ONE handle are serialised inside the library (a
  * per-handle mutex: the handle owns the call's pinned staging); calls on different handles, each with its own scratch
- * and stream, run concurrently.  The environment switch ACOSS_SCORER_F64 (non-empty, not "0": float64 kernels only) is
- * read once, when the handle is made. */
+ * and stream, run concurrently.  Environment switches (the same names the Python engine reads; README.md "Switches"):
+ * ACOSS_PLANAR32=0 (float64 kernels only) and ACOSS_KEYS16=0 (32-bit instead of 16-bit keys for the float32 filter) are read
+ * once, when the handle is made; ACOSS_DP_Q16=0 and ACOSS_DP_ONE_SWEEP=1 (alignment kernels) once per process. */
 typedef struct acoss_corpus acoss_corpus;
 int acoss_corpus_create(const double *feats, const int64_t *frame_off, int n_songs, int d, const double *gchroma,
                         int nbins, acoss_corpus **out);

@@ -61,3 +61,6 @@ def test_integer_qmax_and_dmax_equal_oracle_on_dense_and_degenerate_masks(orc):
                 orc.qmax(Bf, D, M, N)
             want = orc.dmax(Bf, D, M, N)
             assert gd[p] == want, (boundary, p, B.shape, gd[p], want)
+        # ... and both recurrences in one sweep (dp_bits_qd16_kernel: the carried (i-3, j-1) term, the second table)
+        q2, d2 = engine.align_bits_qd(bits, batch, boundary=boundary)
+        assert np.array_equal(q2.cpu().numpy(), got) and np.array_equal(d2.cpu().numpy(), gd), boundary

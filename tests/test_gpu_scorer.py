@@ -158,3 +158,35 @@ def test_scorer_handles_run_concurrently_and_one_handle_serialises(lib, orc):
     finally:
         for h in handles:
             lib.acoss_corpus_destroy(h)
+
+
+def test_first_product_call_makes_one_scratch_allocation_and_no_trial_batches(monkeypatch):
+    """engine.serra09_scores on a fresh process state: the scorer's scratch is ONE plain allocation and the C scorer is entered
+    exactly once (rounds 2-3 allocated several candidates and timed trial batches in each: retired with the row-band kernel)."""
+    import torch
+    from acoss_amd import engine, synth
+    engine.require_gpu()
+    engine.release_scratch()
+    ch = synth.make_corpus(6, 2, seed=3, lengths=lambda r: r.integers(200, 420))
+    corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = synth.all_pairs(ch.n_songs)
+    lib = engine._lib.load()
+    calls, allocs = [], []
+    real_scores, real_empty = lib.acoss_serra09_scores, torch.empty
+
+    def counting_scores(*a):
+        calls.append(1)
+        return real_scores(*a)
+
+    def counting_empty(*a, **kw):
+        t = real_empty(*a, **kw)
+        if t.is_cuda and t.dtype == torch.uint8:
+            allocs.append(t.numel())
+        return t
+    monkeypatch.setattr(lib, "acoss_serra09_scores", counting_scores)
+    monkeypatch.setattr(engine.torch, "empty", counting_empty)
+    got = engine.serra09_scores(corpus, pairs)
+    assert len(calls) == 1 and len(allocs) == 1, (calls, allocs)
+    again = engine.serra09_scores(corpus, pairs)                     # the scratch is reused
+    assert len(calls) == 2 and len(allocs) == 1
+    assert np.array_equal(got["qmax"], again["qmax"]) and np.max(got["qmax"]) > 0

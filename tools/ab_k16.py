@@ -13,7 +13,7 @@ libs = {"base": _lib.load()}
 for a in args:
     n, pth = a.split("=", 1)
     libs[n] = ctypes.CDLL(os.path.abspath(pth))
-NAMES = ["acoss_crp_keys16_batch", "acoss_mask_bits_keys16_batch", "acoss_align_bits_batch"]
+NAMES = ["acoss_crp_keys16_batch", "acoss_mask_bits_keys16_batch", "acoss_align_bits_batch", "acoss_align_bits_qd_batch"]
 for lib in libs.values():
     for fn in NAMES:
         f = getattr(lib, fn)
@@ -53,25 +53,32 @@ def align(lib, kind, out, boundary):
     assert lib.acoss_align_bits_batch(kind, P(bits), P(batch.descs_dev), batch.K, 9, batch.max_nx, batch.max_ny, boundary, None, P(out), st()) == 0
 
 
+def align_qd(lib, oq, od):
+    assert lib.acoss_align_bits_qd_batch(P(bits), P(batch.descs_dev), batch.K, 9, batch.max_nx, batch.max_ny, 1, None, P(oq), P(od), st()) == 0
+
+
+sq2, sd2 = sq.clone(), sd.clone()
 res = {}
 order = list(libs)
 for rnd in range(7):
     for name in (order if rnd % 2 else order[::-1]):
         lib = libs[name]
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(7)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(8)]
         ev[0].record(); strip(lib)
         ev[1].record(); mask(lib, 2)
         ev[2].record(); mask(lib, 3)
         ev[3].record(); mask(lib, 1)
         ev[4].record(); align(lib, 0, sq, 0)
         ev[5].record(); align(lib, 1, sd, 1)
-        ev[6].record()
+        ev[6].record(); align_qd(lib, sq2, sd2)
+        ev[7].record()
         torch.cuda.synchronize()
+        assert torch.equal(sq2, ref_q) and torch.equal(sd2, ref_d), "one-sweep scores differ in build %s" % name
         assert torch.equal(bits, ref_bits), "mask bits differ in build %s" % name
         assert torch.equal(sq, ref_q) and torch.equal(sd, ref_d), "scores differ in build %s" % name
         if rnd:
-            res.setdefault(name, []).append([ev[i].elapsed_time(ev[i + 1]) for i in range(6)])
-print("%-12s %8s %8s %8s %10s %8s %8s   (ms per %d pairs, medians of 6)" % ("build", "strip", "rows", "cols", "mask_bits", "qmax", "dmax", K))
+            res.setdefault(name, []).append([ev[i].elapsed_time(ev[i + 1]) for i in range(7)])
+print("%-12s %8s %8s %8s %10s %8s %8s %8s   (ms per %d pairs, medians of 6)" % ("build", "strip", "rows", "cols", "mask_bits", "qmax", "dmax", "q+d call", K))
 for name in order:
     m = np.median(np.array(res[name]), axis=0)
-    print("%-12s %8.3f %8.3f %8.3f %10.3f %8.3f %8.3f" % ((name,) + tuple(m)))
+    print("%-12s %8.3f %8.3f %8.3f %10.3f %8.3f %8.3f %8.3f" % ((name,) + tuple(m)))
