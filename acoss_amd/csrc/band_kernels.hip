@@ -895,14 +895,7 @@ int acoss_mask_bits_fused_batch(const float *pk, const float *band, const double
     const int64_t blocks = (int64_t)K * (runs_m + runs_n);
     if (blocks > 0x7fffffffLL) { set_error("mask_bits_fused_batch: batch too large"); return ACOSS_ENOTSUP; }
     ACOSS_HIP(hipMemsetAsync(bw.counter, 0, 256, st));
-    int dev_mode = 0;
-#ifdef ACOSS_PROBES
-    const char *dm = getenv("ACOSS_BAND_MODE");       // development ablations (see the kernel)
-    dev_mode = dm ? atoi(dm) : 0;
-    if (d == 12 && getenv("ACOSS_BAND_STAMP")) {
-        hipLaunchKernelGGL((crp_band_kernel<12, true>), dim3((unsigned)blocks), dim3(64 * BD_WAVES), 0, st, pk, descs, runs_m, runs_n, run_bands, kv, mode, bw, dev_mode);
-    } else
-#endif
+    const int dev_mode = 0;      // (development ablations of the kernel: tools removed in round 4)
     if (d == 12) hipLaunchKernelGGL(crp_band_kernel<12>, dim3((unsigned)blocks), dim3(64 * BD_WAVES), 0, st, pk, descs, runs_m, runs_n, run_bands, kv, mode, bw, dev_mode);
     else hipLaunchKernelGGL(crp_band_kernel<13>, dim3((unsigned)blocks), dim3(64 * BD_WAVES), 0, st, pk, descs, runs_m, runs_n, run_bands, kv, mode, bw, dev_mode);
     int rc = launch_check("crp_band_kernel");
@@ -916,18 +909,6 @@ int acoss_mask_bits_fused_batch(const float *pk, const float *band, const double
     return launch_check("combine_planes_kernel");
 }
 
-#ifdef ACOSS_PROBES
-// development: read and reset the phase cycle sums of the STAMP build (ACOSS_BAND_STAMP=1); not part of the public ABI
-int acoss_dev_band_stamps(unsigned long long *out, int n)
-{
-    unsigned long long host[BD_NSTAMP] = {};
-    ACOSS_HIP(hipMemcpyFromSymbol(host, HIP_SYMBOL(g_band_stamps), sizeof(host)));
-    for (int i = 0; i < n && i < BD_NSTAMP; i++) out[i] = host[i];
-    unsigned long long zero[BD_NSTAMP] = {};
-    ACOSS_HIP(hipMemcpyToSymbol(HIP_SYMBOL(g_band_stamps), zero, sizeof(zero)));
-    return ACOSS_OK;
-}
-#endif  // ACOSS_PROBES
 
 // rows the last acoss_mask_bits_fused_batch on `work` could not decide in its own kernel (device int, valid once the
 // stream has run): more than side_rows means some were dropped and the call must be repeated with a larger side buffer

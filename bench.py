@@ -72,6 +72,8 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="headline only (no comparison paths, no config 3-5 blocks)")
     ap.add_argument("--cpu-pairs", type=int, default=0, help="CPU baseline sample size (0 = auto)")
+    ap.add_argument("--no-child-ranks", action="store_true",
+                    help="side blocks start no child processes (the 4-rank rehearsal of the config-3 job is skipped: for runs under a profiler)")
     ap.add_argument("--config3-rank", default=None, metavar="OUT.json",
                     help="(internal) run the BASELINE config-3 job as one rank of a torch.distributed group and have rank 0 write its summary")
     args = ap.parse_args()
@@ -465,7 +467,7 @@ def config3_rank_main(out_path):
     dist.destroy_process_group()
 
 
-def extras_config3(engine, synth, oracle, threads, torch):
+def extras_config3(engine, synth, oracle, threads, torch, child_ranks=True):
     """BASELINE config 3 (DA-TACOS benchmark_subset shape, Serra09 with constrained Smith-Waterman): a 2000-song sample of
     synth.config3's distribution, qmax + dmax + swc through the one-call scorer."""
     ch = synth.config3(n_cliques=133, singletons=271)
@@ -502,6 +504,8 @@ def extras_config3(engine, synth, oracle, threads, torch):
         job.update(one)
         engine.release_scratch()
         torch.cuda.empty_cache()
+        if not child_ranks:
+            raise StopIteration
         import socket
         sk = socket.socket()
         sk.bind(("127.0.0.1", 0))
@@ -527,6 +531,8 @@ def extras_config3(engine, synth, oracle, threads, torch):
         else:
             job["sharded_4_ranks"] = {"error": (res.stderr or res.stdout)[-600:]}
             job["identical_1_vs_4_ranks"] = None
+    except StopIteration:
+        job["sharded_4_ranks"] = "skipped (--no-child-ranks)"
     except Exception as exc:
         job["error"] = "%s: %s" % (type(exc).__name__, exc)
     finally:
@@ -1171,7 +1177,7 @@ def main():
         for key, fn in (("full_job", lambda: extras_full_job(corpus_h, torch, tmpdir)),
                         ("plugin_similarity", lambda: extras_plugin_similarity(corpus_h, all_pairs, oracle, threads, torch, tmpdir)),
                         ("scatter_chain", lambda: extras_scatter_chain(engine, oracle, torch)),
-                        ("config3", lambda: extras_config3(engine, synth, oracle, threads, torch)),
+                        ("config3", lambda: extras_config3(engine, synth, oracle, threads, torch, child_ranks=not args.no_child_ranks)),
                         ("early_snf", lambda: extras_early_snf(engine, synth, torch)),
                         ("ftm2d", lambda: extras_ftm2d(engine, torch)),
                         ("scatter_csm", lambda: extras_scatter_csm(engine, oracle, torch))):
