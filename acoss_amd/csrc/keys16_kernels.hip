@@ -263,7 +263,8 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
 // ---- refinement ------------------------------------------------------------------------------------------------------------
 // One wave per side-buffer slot: exact float64 values of every cell whose 16-bit key the winner's error band can reach
 // (fix_row_band; the general bit-serial selection when more than 64 cells are in reach), cells with smaller keys are selected.
-__global__ __launch_bounds__(64) void select_fix_side16_kernel(const double *__restrict__ feats, const double *__restrict__ norms, int d,
+template <typename FT>
+__global__ __launch_bounds__(64) void select_fix_side16_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
                                                                const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
                                                                ThreshWork w, const uint32_t *__restrict__ koff)
 {
@@ -295,9 +296,9 @@ __global__ __launch_bounds__(64) void select_fix_side16_kernel(const double *__r
 
 // rows / columns that found no room in the side buffer (never, with its 2 % capacity, on real features): the same refinement
 // from the key plane itself
-template <int DIR>
-__global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__restrict__ keys16, const double *__restrict__ feats,
-                                                            const double *__restrict__ norms, int d, const acoss_pair_desc *__restrict__ descs,
+template <int DIR, typename FT>
+__global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__restrict__ keys16, const FT *__restrict__ feats,
+                                                            const FT *__restrict__ norms, int d, const acoss_pair_desc *__restrict__ descs,
                                                             int win, double kv, int k_mode, ThreshWork w, const uint32_t *__restrict__ koff,
                                                             int groups, int64_t total)
 {
@@ -337,10 +338,13 @@ int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual
 
 using namespace acoss;
 
-extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
-                                            const float *f32, const float *n32, const double *feats, const double *norms, int d,
-                                            const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
-                                            int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
+// FT = the type of the corpus whose EXACT windowed sums the masks are defined by (planar_select.h: exact_term): double for
+// float64 features, float for float32 features (then feats / norms are the very arrays the filter was computed from)
+template <typename FT>
+static int mask_bits_keys16_impl(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                 const float *f32, const float *n32, const FT *feats, const FT *norms, int d,
+                                 const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
+                                 int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
 {
     if (!keys16 || !band || !koff || !xp || !f32 || !n32 || !feats || !norms || !descs || !bits || !work || K < 0 || max_nx < win ||
         max_ny < win || kappa < 0.0) {
@@ -390,15 +394,37 @@ extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float 
         if (rc) return rc;
         if (mutual == 3) return ACOSS_OK;
     }
-    hipLaunchKernelGGL(select_fix_side16_kernel, dim3((unsigned)w.side_cap), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
+    hipLaunchKernelGGL(select_fix_side16_kernel<FT>, dim3((unsigned)w.side_cap), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
     rc = launch_check("select_fix_side16_kernel");
     if (rc) return rc;
     const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
-    hipLaunchKernelGGL(select_fix_k16_kernel<0>, dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm, (int64_t)K * gm);
-    if (mutual) hipLaunchKernelGGL(select_fix_k16_kernel<1>, dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn, (int64_t)K * gn);
+    hipLaunchKernelGGL((select_fix_k16_kernel<0, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm, (int64_t)K * gm);
+    if (mutual) hipLaunchKernelGGL((select_fix_k16_kernel<1, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn, (int64_t)K * gn);
     rc = launch_check("select_fix_k16_kernel (overflow)");
     if (rc) return rc;
     return launch_combine_bits(descs, K, win, mutual, w, bits, st);
+}
+
+extern "C" int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                            const float *f32, const float *n32, const double *feats, const double *norms, int d,
+                                            const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
+                                            int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
+{
+    return mask_bits_keys16_impl<double>(keys16, band, koff, xp, f32, n32, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual,
+                                         bits, work, work_bytes, stream);
+}
+
+// The same for a corpus of float32 features (the reference's mfcc_htk / hpcp: CRPUtils.py:82, :40-41): the masks equal those of
+// acoss_crp_batch_f32 + acoss_mask_bits_batch.  f32 / n32 are the corpus itself and its norms (acoss_frame_norms_f32) -- not a
+// centred copy: the filter's cross-similarity values are then bit for bit the exact path's, and only the root-square and the
+// float32 window sum separate the two (|T~ - T| <= 7 u T: inside the band of acoss_mask_bits_planar32_batch).
+extern "C" int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                                const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K, int win,
+                                                int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
+                                                size_t work_bytes, void *stream)
+{
+    return mask_bits_keys16_impl<float>(keys16, band, koff, xp, f32, n32, f32, n32, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits,
+                                        work, work_bytes, stream);
 }
 
 #ifdef ACOSS_PROBES

@@ -423,22 +423,35 @@ __device__ inline int knn_count(int k_mode, double kv, int len)
 }
 
 // ---- fix-up: rows / columns whose winner shares its high word -----------------------------------------------
-// One windowed sum, exactly as crp_strip_kernel forms it: dot product as an FMA chain over the bins of the rolled
-// x frame, C = max(fma(-2, dot, |x|^2 + |y|^2), 0), the window's C values added in order (the matrix-core and VALU
-// forms of that chain agree bit for bit: tests/test_gpu_fast_path.py).
-__device__ inline double planar_exact_value(const double *__restrict__ feats, const double *__restrict__ norms, int d,
+// One term of a windowed sum as the EXACT path defines it, from the dot product of a frame pair and the two squared norms:
+//   float64 features (crema chroma): C = max(fma(-2, dot, |x|^2 + |y|^2), 0) in float64 (crp_strip_kernel's arithmetic);
+//   float32 features (the reference's mfcc_htk / hpcp: get_csm follows its inputs' dtype, CRPUtils.py:82, and sliding_csm
+//   squares in that dtype before it promotes, :40-41): c in float32, r = sqrtf(max(c, 0)), the term is (double)(r * r) --
+//   crp_kernel<float>'s arithmetic, which the float32 filter's values differ from only by the root-square and the float32
+//   window sum (round 4: the 16-bit-key path for float32 corpora).
+__device__ inline double exact_term(double dot, double nsum) { return fmax(fma(-2.0, dot, nsum), 0.0); }
+__device__ inline double exact_term(float dot, float nsum)
+{
+    const float r = sqrtf(fmaxf(fmaf(-2.0f, dot, nsum), 0.0f));
+    return (double)(r * r);
+}
+
+// One windowed sum, exactly: dot product as an FMA chain over the bins of the rolled x frame (the matrix-core and VALU forms
+// of that chain agree bit for bit: tests/test_gpu_fast_path.py), exact_term(), the window's terms added in order in float64.
+template <typename FT>
+__device__ inline double planar_exact_value(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
                                             const acoss_pair_desc &ds, int win, int i, int j)
 {
     double s = 0.0;
     for (int k = 0; k < win; k++) {
-        const double *x = feats + (ds.x_row0 + i + k) * d, *y = feats + (ds.y_row0 + j + k) * d;
-        double acc = 0.0;
+        const FT *x = feats + (ds.x_row0 + i + k) * d, *y = feats + (ds.y_row0 + j + k) * d;
+        FT acc = 0;
         for (int b = 0; b < d; b++) {
             int src = b - ds.shift;
             if (src < 0) src += d;
             acc = fma(x[src], y[b], acc);
         }
-        s += fmax(fma(-2.0, acc, norms[ds.x_row0 + i + k] + norms[ds.y_row0 + j + k]), 0.0);
+        s += exact_term(acc, norms[ds.x_row0 + i + k] + norms[ds.y_row0 + j + k]);
     }
     return s;
 }
@@ -458,9 +471,9 @@ __device__ inline uint64_t shifted_plane_word(uint64_t mine, int plane_shift, in
 // key_at(q): the uint32 key of position q of the row / column (its source: the key matrix, or a compact copy of the row).
 // thr_hi: the high word the selection left for this row; thr / cut (may be null): where the final threshold goes.
 // (have_range: [blo, bhi] given by the caller -- the 16-bit keys of keys16.h; else derived from thr_hi and the pair's band)
-template <int DIR, int E, typename KeyAt>
-__device__ inline void fix_row_generic_impl(KeyAt key_at, unsigned thr_hi, bool have_range, unsigned blo, unsigned bhi, const double *__restrict__ feats,
-                                       const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+template <int DIR, int E, typename KeyAt, typename FT>
+__device__ inline void fix_row_generic_impl(KeyAt key_at, unsigned thr_hi, bool have_range, unsigned blo, unsigned bhi, const FT *__restrict__ feats,
+                                       const FT *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                        const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     // the selection kernel left the high word the tied elements share: only those few need their exact value;
@@ -508,17 +521,17 @@ __device__ inline void fix_row_generic_impl(KeyAt key_at, unsigned thr_hi, bool 
     }
 }
 
-template <int DIR, int E, typename KeyAt>
-__device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
-                                       const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+template <int DIR, int E, typename KeyAt, typename FT>
+__device__ inline void fix_row_generic(KeyAt key_at, unsigned thr_hi, const FT *__restrict__ feats,
+                                       const FT *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                        const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     fix_row_generic_impl<DIR, E>(key_at, thr_hi, false, 0u, 0u, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane, plane_shift);
 }
 
-template <int DIR, int E, typename KeyAt>
-__device__ inline void fix_row_generic_range(KeyAt key_at, unsigned blo, unsigned bhi, const double *__restrict__ feats,
-                                             const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+template <int DIR, int E, typename KeyAt, typename FT>
+__device__ inline void fix_row_generic_range(KeyAt key_at, unsigned blo, unsigned bhi, const FT *__restrict__ feats,
+                                             const FT *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                              const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane)
 {
     fix_row_generic_impl<DIR, E>(key_at, 1u, true, blo, bhi, feats, norms, d, ds, win, w, p, which, len, k, thr, cut, lane, 0);
@@ -538,9 +551,9 @@ struct FixSmem {
     unsigned char sel[64];
 };
 
-template <int DIR, int E, typename KeyAt>
-__device__ inline bool fix_row_band_range(FixSmem &sm, KeyAt key_at, unsigned blo, unsigned bhi, const double *__restrict__ feats,
-                                    const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+template <int DIR, int E, typename KeyAt, typename FT>
+__device__ inline bool fix_row_band_range(FixSmem &sm, KeyAt key_at, unsigned blo, unsigned bhi, const FT *__restrict__ feats,
+                                    const FT *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                     const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     if (win != 9 || d > FIX_MAXD) return false;
@@ -570,21 +583,21 @@ __device__ inline bool fix_row_band_range(FixSmem &sm, KeyAt key_at, unsigned bl
         if (lane < 63 && el < n) {
             const int pos = sm.pos[el];
             const int i = DIR == 0 ? which : pos, j = DIR == 0 ? pos : which;
-            const double *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
-            double xv[FIX_MAXD], yv[FIX_MAXD];
+            const FT *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
+            FT xv[FIX_MAXD], yv[FIX_MAXD];
 #pragma unroll
             for (int b = 0; b < FIX_MAXD; b++) {
                 int src = b - ds.shift;
                 if (src < 0) src += d;
-                xv[b] = b < d ? x[src] : 0.0;
-                yv[b] = b < d ? y[b] : 0.0;
+                xv[b] = b < d ? x[src] : (FT)0;
+                yv[b] = b < d ? y[b] : (FT)0;
             }
-            const double nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
-            double acc = 0.0;
+            const FT nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
+            FT acc = 0;
 #pragma unroll
             for (int b = 0; b < FIX_MAXD; b++)
                 if (b < d) acc = fma(xv[b], yv[b], acc);
-            sm.cval[g * 9 + kk] = fmax(fma(-2.0, acc, nn), 0.0);
+            sm.cval[g * 9 + kk] = exact_term(acc, nn);
         }
         __syncthreads();
         if (lane < 7 && c0 + lane < n) {
@@ -632,9 +645,9 @@ __device__ inline bool fix_row_band_range(FixSmem &sm, KeyAt key_at, unsigned bl
     return true;
 }
 
-template <int DIR, int E, typename KeyAt>
-__device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, const double *__restrict__ feats,
-                                    const double *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
+template <int DIR, int E, typename KeyAt, typename FT>
+__device__ inline bool fix_row_band(FixSmem &sm, KeyAt key_at, unsigned thr_hi, const FT *__restrict__ feats,
+                                    const FT *__restrict__ norms, int d, const acoss_pair_desc &ds, int win,
                                     const ThreshWork &w, int p, int which, int len, int k, uint64_t *thr, int *cut, int lane, int plane_shift = 0)
 {
     if (thr_hi == 0u) return false;

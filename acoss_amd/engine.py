@@ -249,10 +249,20 @@ def crp_planar(corpus, batch, xp, out=None):
 
 
 def float32_copy(corpus):
-    """(features, squared norms) of a float64 corpus, centred and rounded to float32, cached on the corpus: the operands
+    """(features, squared norms) of a float64 corpus, centred and rounded to float32 (of a float32 corpus: the corpus itself,
+    see below), cached on the corpus: the operands
     of the approximate strip kernel (crp_planar32).  Every entry has the corpus mean subtracted first: distances between
     frames do not change (the shift is the same in every bin, so it commutes with the OTI rotation), but the squared
     norms -- the scale of the float32 error bound -- shrink to the variance part (about a third for chroma)."""
+    if getattr(corpus, "_f32", None) is None and corpus.dtype == np.float32:
+        # a float32 corpus (the reference's mfcc_htk / hpcp) IS its own filter operand: its exact path runs in float32 on
+        # these very values (CRPUtils.py:82, :40-41), so the filter's cross-similarity values are bit for bit the exact ones
+        n64 = corpus.norms.to(torch.float64)
+        top = float(n64.max().item()) if n64.numel() else 0.0
+        corpus._f32_ok = bool(np.isfinite(top) and top > 0.0 and bool(torch.isfinite(corpus.feats).all().item()))
+        corpus._f32_scale2 = 1.0
+        corpus._f32 = (corpus.feats, corpus.norms)
+        corpus._f32_norms64 = n64.cpu().numpy()
     if getattr(corpus, "_f32", None) is None:
         mu = corpus.feats.mean()
         centred = corpus.feats - mu
@@ -385,17 +395,24 @@ def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True
     need = int(lib.acoss_mask_bits_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
     if work is None or work.numel() < need:
         work = torch.empty(need, dtype=torch.uint8, device=keys16.device)
+    mcode = {"rows_kernel_only": 2, "cols_kernel_only": 3}.get(mutual) if isinstance(mutual, str) else int(bool(mutual))
+    if corpus.dtype == np.float32:
+        # float32 features: the exact values behind the masks are the float32-input ones (sum of (double)(sqrtf(c)^2))
+        check(lib.acoss_mask_bits_keys16_f32_batch(_ptr(keys16), _ptr(band), _ptr(koff), _ptr(xp32), _ptr(f32), _ptr(n32), corpus.d,
+                                                   _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny, float(kappa),
+                                                   mcode, _ptr(out), _ptr(work), work.numel(), _stream()), "mask_bits_keys16_f32_batch")
+        return out, work
     check(lib.acoss_mask_bits_keys16_batch(_ptr(keys16), _ptr(band), _ptr(koff), _ptr(xp32), _ptr(f32), _ptr(n32), _ptr(corpus.feats),
                                            _ptr(corpus.norms), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx,
-                                           batch.max_ny, float(kappa), {"rows_kernel_only": 2, "cols_kernel_only": 3}.get(mutual) if isinstance(mutual, str) else int(bool(mutual)), _ptr(out), _ptr(work),
+                                           batch.max_ny, float(kappa), mcode, _ptr(out), _ptr(work),
                                            work.numel(), _stream()), "mask_bits_keys16_batch")
     return out, work
 
 
 def keys16_supported(corpus, batch):
-    """float64 chroma / MFCC-sized features, the reference's window, matrices up to 1024 x 1024."""
-    return (planar_supported(corpus, batch) and batch.max_nx - batch.win + 1 <= 1024 and batch.max_ny - batch.win + 1 <= 1024
-            and planar32_usable(corpus))
+    """float64 or float32 chroma / MFCC-sized features, the reference's window, matrices up to 1024 x 1024."""
+    return (corpus.d in (12, 13) and batch.win == 9 and batch.max_nx - batch.win + 1 <= 1024
+            and batch.max_ny - batch.win + 1 <= 1024 and planar32_usable(corpus))
 
 
 def packed32(corpus):
@@ -790,6 +807,12 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             oti(corpus, batch)
         planar = planar_supported(corpus, batch)
         use32 = planar and (planar32_default() if approx32 is None else bool(approx32)) and planar32_usable(corpus)
+        # float32 corpora (the reference's mfcc_htk): the same filter on 16-bit keys with the corpus itself as its operand,
+        # refined with the exact float32-input arithmetic (round 4); everything else about the batch as for float64
+        filter32 = (corpus.dtype == np.float32 and (planar32_default() if approx32 is None else bool(approx32)) and keys16_default()
+                    and not fused_default() and keys16_supported(corpus, batch))
+        if filter32:
+            planar = use32 = True
         fused = use32 and fused_default() and fused_supported(corpus, batch)
         # scratch buffers live across calls (grow-only): a fresh 16-34 GB allocation per call costs more than the batch
         xp = None if use32 else pack_x(corpus, batch, out=_scratch("xp", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), corpus.feats.dtype, corpus.device))

@@ -306,6 +306,17 @@ int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, cons
                                  const float *f32, const float *n32, const double *feats, const double *norms, int d,
                                  const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa,
                                  int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);
+/* The 16-bit-key filter for a corpus of FLOAT32 features (round 4; the reference's mfcc_htk / hpcp: get_csm follows its inputs'
+ * dtype, CRPUtils.py:82, and sliding_csm squares in that dtype before it promotes to float64, :40-41).  f32 / n32 are the corpus
+ * itself and its norms (acoss_frame_norms_f32), xp = acoss_pack_x_f32 of them, keys16 = acoss_crp_keys16_batch on them, band /
+ * koff as above from the corpus' own norms: no centred copy -- the filter's cross-similarity values are then bit for bit the
+ * exact path's and only the root-square and the float32 window sum separate the two (within the band's slope).  What the keys
+ * and recomputed float32 values cannot decide is finished with the exact float32-input arithmetic
+ * (sum over the window of (double)(sqrtf(max(c, 0))^2)): masks identical to acoss_crp_batch_f32 + acoss_mask_bits_batch. */
+int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
+                                     const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K, int win,
+                                     int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
+                                     size_t work_bytes, void *stream);
 /* The product path: get_csm + sliding_csm + csm_to_binary_mutual (CRPUtils.py:67-84, :24-45, :201-219) without any
  * matrix in HBM.  One kernel forms a 24-row band of a pair's windowed sums in float32 on the matrix cores, keeps the
  * band's keys in registers, selects each row's k-th smallest and writes only the row's bit plane; run on (x, y) it

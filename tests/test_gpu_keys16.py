@@ -221,3 +221,75 @@ def test_pairs_far_below_the_corpus_scale(eng):
     a = eng.serra09_scores(corpus, pairs)
     b = eng.serra09_scores(corpus, pairs, approx32=False)
     assert np.array_equal(a["qmax"], b["qmax"]) and np.array_equal(a["dmax"], b["dmax"])
+
+
+def _f32_reference_masks(eng, corpus, batch, kappa, mutual):
+    """The float32-input chain as the staged path runs it (crp_kernel<float>: CRPUtils.py:82 + :40-41, then the float64
+    selection): the definition the filter must reproduce."""
+    xp = eng.pack_x(corpus, batch)
+    T = eng.crp(corpus, batch, xp, sqrt_out=False)
+    return eng.mask_bits(T, batch, kappa, mutual=mutual)[0]
+
+
+@pytest.mark.parametrize("d,do_oti", [(13, False), (12, True)])
+def test_float32_corpus_masks_equal_the_float32_input_chain(eng, d, do_oti):
+    """Round 4: the 16-bit-key filter for corpora of float32 features (the reference's mfcc_htk, 13-d, and essentia hpcp, 12-d
+    with OTI).  Operand = the corpus itself, so the cross-similarity values are the exact path's; tiers 2 and 3 must
+    reproduce the float32-input windowed sums (sum of (double)(sqrtf(c)^2)).  Masks against crp_kernel<float> + float64
+    selection, bit for bit: smooth random walks, features with a large common offset (window norm sums far above the
+    distances: thresholds fall into the coarse keys or below the key range -- handed over), tiny and huge magnitudes, exact
+    ties (repeated frames), ragged lengths, both kappa conventions."""
+    rng = np.random.default_rng(100 + d)
+    lens = [60, 131, 257, 400, 1032, 333]
+    walk = [np.cumsum(rng.standard_normal((n, d)), axis=0).astype(np.float32) for n in lens]
+    fams = {"walk": walk,
+            "offset": [(w + np.float32(200.0)).astype(np.float32) for w in walk],
+            "tiny": [(w * np.float32(1e-12)).astype(np.float32) for w in walk],
+            "huge": [(w * np.float32(1e+12)).astype(np.float32) for w in walk],
+            "ties": [np.tile(w[:11], (len(w) // 11 + 1, 1))[:len(w)].copy() for w in walk]}
+    pairs = np.array([(0, 1), (1, 2), (2, 3), (3, 4), (4, 5), (5, 0), (4, 4), (2, 0)], dtype=np.int32)
+    for name, songs in fams.items():
+        if d == 12:
+            songs = [np.abs(s) for s in songs]
+        feats = np.concatenate(songs)
+        off = np.cumsum([0] + [len(s) for s in songs]).astype(np.int64)
+        gc = np.stack([s.astype(np.float64).sum(0) / max(float(s.astype(np.float64).sum(0).max()), 1e-300) for s in songs]) if do_oti else None
+        corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+        assert corpus.dtype == np.float32
+        batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+        if do_oti:
+            eng.oti(corpus, batch)
+        if not eng.keys16_supported(corpus, batch):
+            assert name in ("huge",)                       # squared norms beyond float32: stays on the staged kernels
+            continue
+        xp32, koff, band, k16 = _chain(eng, corpus, batch)
+        for kappa, mutual in ((0.095, True), (0.095, False), (7, True)):
+            want = _f32_reference_masks(eng, corpus, batch, kappa, mutual)
+            got, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, kappa, mutual=mutual)
+            for p in range(batch.K):
+                a, b = eng.unpack_mask_bits(got, batch, p), eng.unpack_mask_bits(want, batch, p)
+                if name == "ties":
+                    # exact ties: both forms cut lowest position first, but their float64 sums of equal terms are formed in the
+                    # same order -- still identical
+                    pass
+                assert np.array_equal(a, b), (name, kappa, mutual, p, int((a != b).sum()))
+
+
+def test_float32_corpus_scores_through_the_engine(eng, orc):
+    """engine.serra09_scores on a float32 corpus takes the filter path and returns the scores of the oracle's float32 chain."""
+    rng = np.random.default_rng(77)
+    lens = [90, 150, 220, 317]
+    songs = [np.cumsum(rng.standard_normal((n, 13)), axis=0).astype(np.float32) for n in lens]
+    feats = np.concatenate(songs)
+    off = np.cumsum([0] + lens).astype(np.int64)
+    corpus = eng.DeviceCorpus(feats, off)
+    pairs = np.array([(i, j) for i in range(4) for j in range(4) if i != j], dtype=np.int32)
+    got = eng.serra09_scores(corpus, pairs, do_oti=False, want=("qmax", "dmax", "swc"))
+    for t, (i, j) in enumerate(pairs):
+        B = orc.csm_to_binary_mutual(orc.sliding_csm(orc.get_csm(songs[i], songs[j]), 9), 0.095)
+        M, N = B.shape
+        Bf = np.ascontiguousarray(B.flatten())
+        D = np.zeros(M * N, dtype=np.float32)
+        q = orc.qmax(Bf, D, M, N) / (M + N)
+        dm = orc.dmax(Bf, D, M, N) / (M + N)
+        assert got["qmax"][t] == q and got["dmax"][t] == dm, (t, i, j)
