@@ -168,11 +168,13 @@ class CoverAlgorithm(object):
             i, j = np.nonzero(~np.eye(n, dtype=bool))            # itertools.permutations order (:168)
         return np.stack([i, j], axis=1).astype(np.int64)
 
-    def all_pairwise(self, parallel=0, n_cores=12, symmetric=False, precomputed=False, batch_pairs=4096):
+    def all_pairwise(self, parallel=0, n_cores=12, symmetric=False, precomputed=False, batch_pairs=1 << 18):
         """
         All pairwise comparisons (CoverAlgorithm.py:138-184).  `parallel` / `n_cores` are accepted
         for call compatibility; the parallelism here is the GPU batch (and, when
         torch.distributed is initialised, one process per GPU over a sharded pair list).
+        batch_pairs: pairs per similarity() call (the plugins split a call into launch batches of their own; a call costs
+        a few milliseconds of host work and one synchronisation, so the default is large).
         """
         tic = time.time()
         dump = "%s_Ds.npz" % self.get_cacheprefix()

@@ -331,6 +331,87 @@ __global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__re
     }
 }
 
+// ---- key offsets for float32 corpora ---------------------------------------------------------------------------------------------
+// For a float64 corpus koff follows from the window norm sums W of the CENTRED copy the filter runs on (engine.keys16_koff): no
+// windowed sum exceeds 2 W and thresholds sit 1.5-6 octaves below it.  A float32 corpus is its own filter operand (no centring:
+// acoss_mask_bits_keys16_f32_batch), and features with a common offset -- real MFCC: the energy-like coefficient -- have raw norm
+// sums far above every distance: a key range hung on them would lie above all thresholds.  But |x - y|^2 <= 2 (|x - m|^2 +
+// |y - m|^2) for ANY vector m, so the range hangs on norms centred PER PAIR, m = the midpoint of the two songs' mean frames
+// (pairs of songs that share an offset are covered too).  One block per pair: mean frames, centred squared norms into LDS, the
+// largest 9-frame window sum of each song -> top = 2 (Wx + Wy) (+ the float32 noise of the raw operands, 2^-17 of the raw norm
+// sums: a value that clamps at the top all the same is merely handed over), koff = the pattern of top 2^-7.
+template <int D>
+__global__ __launch_bounds__(256) void k16_koff_pair_kernel(const float *__restrict__ xp, int max_nx, const float *__restrict__ f32,
+                                                            const float *__restrict__ n32, const acoss_pair_desc *__restrict__ descs,
+                                                            int win, uint32_t *__restrict__ koff)
+{
+    __shared__ float mean[2][16];
+    __shared__ float cn[2][1040 + 16];             // centred squared norms of the x and y frames
+    __shared__ unsigned wmax[4];                   // [song] centred, [2 + song] raw: window-sum maxima as float bit patterns (>= 0)
+    const int p = blockIdx.x;
+    const acoss_pair_desc ds = descs[p];
+    const int tid = threadIdx.x;
+    if (ds.nx > 1040 || ds.ny > 1040) { if (tid == 0) koff[p] = 0u; return; }      // (block-uniform; the 16-bit path stops at 1032 frames)
+    if (tid < 32) mean[tid >> 4][tid & 15] = 0.0f;
+    if (tid < 4) wmax[tid] = 0u;
+    __syncthreads();
+    const float *xs = xp + (int64_t)p * max_nx * 16;                 // x frames rotated by the OTI: 16 floats each
+    const float *ys = f32 + ds.y_row0 * D;
+    auto frame = [&](int song, int f, int b) { return song == 0 ? xs[(int64_t)f * 16 + b] : ys[(int64_t)f * D + b]; };
+    for (int song = 0; song < 2; song++) {
+        const int n = song == 0 ? ds.nx : ds.ny;
+        float acc[D];
+#pragma unroll
+        for (int b = 0; b < D; b++) acc[b] = 0.0f;
+        for (int f = tid; f < n; f += 256) {
+#pragma unroll
+            for (int b = 0; b < D; b++) acc[b] += frame(song, f, b);
+        }
+#pragma unroll
+        for (int b = 0; b < D; b++) atomicAdd(&mean[song][b], acc[b] / (float)n);
+    }
+    __syncthreads();
+    float m[D];
+#pragma unroll
+    for (int b = 0; b < D; b++) m[b] = 0.5f * (mean[0][b] + mean[1][b]);
+    for (int song = 0; song < 2; song++) {
+        const int n = song == 0 ? ds.nx : ds.ny;
+        for (int f = tid; f < n; f += 256) {
+            float q = 0.0f;
+#pragma unroll
+            for (int b = 0; b < D; b++) {
+                const float v = frame(song, f, b) - m[b];
+                q = fmaf(v, v, q);
+            }
+            cn[song][f] = q;
+        }
+    }
+    __syncthreads();
+    for (int song = 0; song < 2; song++) {
+        const int n = song == 0 ? ds.nx : ds.ny;
+        const float *raw = song == 0 ? nullptr : n32 + ds.y_row0;
+        float best = 0.0f, best_raw = 0.0f;
+        for (int i = tid; i + win <= n; i += 256) {
+            float w = 0.0f, wr = 0.0f;
+            for (int k = 0; k < win; k++) {
+                w += cn[song][i + k];
+                wr += song == 0 ? xs[(int64_t)(i + k) * 16 + D] : raw[i + k];
+            }
+            best = fmaxf(best, w);
+            best_raw = fmaxf(best_raw, wr);
+        }
+        if (best == best) atomicMax(&wmax[song], __float_as_uint(fmaxf(best, 0.0f)));
+        else atomicMax(&wmax[song], 0x7f800000u);                    // a NaN anywhere: no usable range
+        atomicMax(&wmax[2 + song], best_raw == best_raw ? __float_as_uint(fmaxf(best_raw, 0.0f)) : 0x7f800000u);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const float wc = __uint_as_float(wmax[0]) + __uint_as_float(wmax[1]), wr = __uint_as_float(wmax[2]) + __uint_as_float(wmax[3]);
+        const float top = fmaf(0x1p-17f, wr, 2.0f * wc * (1.0f + 0x1p-10f));
+        koff[p] = (top > 0x1p-100f && top < INFINITY) ? __float_as_uint(top) + 1u - (7u << 23) : 0u;
+    }
+}
+
 // defined in crp_kernels.hip
 int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st);
 
@@ -425,6 +506,23 @@ extern "C" int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const fl
 {
     return mask_bits_keys16_impl<float>(keys16, band, koff, xp, f32, n32, f32, n32, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits,
                                         work, work_bytes, stream);
+}
+
+// koff[pair] for acoss_crp_keys16_batch / acoss_mask_bits_keys16_f32_batch on a float32 corpus (k16_koff_pair_kernel: the key
+// range hung on norms centred per pair).  xp / f32 / n32 / descs: exactly what acoss_crp_keys16_batch will be given.
+extern "C" int acoss_keys16_koff_f32_batch(const float *xp, const float *f32, const float *n32, int d, const acoss_pair_desc *descs,
+                                           int K, int win, int max_nx, int max_ny, uint32_t *koff, void *stream)
+{
+    if (!xp || !f32 || !n32 || !descs || !koff || K < 0 || max_nx < win || max_ny < win) {
+        set_error("keys16_koff_f32_batch: bad argument");
+        return ACOSS_EINVAL;
+    }
+    if ((d != 12 && d != 13) || win != 9) { set_error("keys16_koff_f32_batch: supports d in {12, 13} and win == 9"); return ACOSS_ENOTSUP; }
+    if (K == 0) return ACOSS_OK;
+    hipStream_t st = (hipStream_t)stream;
+    if (d == 12) hipLaunchKernelGGL(k16_koff_pair_kernel<12>, dim3((unsigned)K), dim3(256), 0, st, xp, max_nx, f32, n32, descs, win, koff);
+    else hipLaunchKernelGGL(k16_koff_pair_kernel<13>, dim3((unsigned)K), dim3(256), 0, st, xp, max_nx, f32, n32, descs, win, koff);
+    return launch_check("k16_koff_pair_kernel");
 }
 
 #ifdef ACOSS_PROBES

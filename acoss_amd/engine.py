@@ -280,6 +280,23 @@ def float32_copy(corpus):
     return corpus._f32
 
 
+def song_variation(corpus):
+    """Per song, the mean squared distance of its frames from the song's mean frame (host float64, cached): the scale the
+    float32 filter's resolution is measured against when two songs of very different loudness meet (serra09_scores_py)."""
+    v = getattr(corpus, "_variation", None)
+    if v is None:
+        f = corpus.feats.to(torch.float64)
+        off = corpus.frame_off
+        v = np.zeros(corpus.n_songs)
+        for s_ in range(corpus.n_songs):
+            a, b = int(off[s_]), int(off[s_ + 1])
+            if b > a:
+                x = f[a:b]
+                v[s_] = float(((x - x.mean(0, keepdim=True)) ** 2).sum(1).mean().item())
+        corpus._variation = v
+    return v
+
+
 def planar32_usable(corpus):
     """False for corpora the float32 copy cannot represent (all-zero or non-finite features): those stay on float64."""
     float32_copy(corpus)
@@ -364,6 +381,8 @@ def keys16_koff(corpus, batch):
     key16 = min(max(k' >> 11, (k' >> 9) -sat 49152), 0xFFFE): 14 mantissa bits over the three octaves below 2 W, 12 over the
     four below those.  The pattern is that of the float32 NOT BELOW 2 W (the kernels rely on koff >= 2 W 2^-7).  Device int32
     tensor (K)."""
+    if corpus.dtype == np.float32:
+        raise AcossError("keys16_koff: a float32 corpus takes its key range from the data (keys16_koff_f32)")
     w = corpus.song_wmax(batch.win)
     sx, sy = batch.descs["song_x"].astype(np.int64), batch.descs["song_y"].astype(np.int64)
     W64 = 2.0 * (w[sx] + w[sy])
@@ -372,6 +391,29 @@ def keys16_koff(corpus, batch):
     bits = W.view(np.uint32).astype(np.int64) - (7 << 23)
     koff = np.where(np.isfinite(W) & (W > np.float32(2.0 ** -100)), bits, 0).astype(np.uint32)
     return torch.from_numpy(koff.view(np.int32).copy()).to(corpus.device)
+
+
+def keys16_koff_f32(corpus, batch, xp32):
+    """koff for a FLOAT32 corpus (its own filter operand, not centred): the key range hung on squared norms centred PER PAIR
+    (|x - y|^2 <= 2 (|x - m|^2 + |y - m|^2) for any m) -- the raw norm sums of features with a common offset (real MFCC) lie
+    far above every distance.  Device int32 tensor (K)."""
+    lib = _lib.load()
+    f32, n32 = float32_copy(corpus)
+    koff = torch.empty(max(batch.K, 1), dtype=torch.int32, device=corpus.device)
+    check(lib.acoss_keys16_koff_f32_batch(_ptr(xp32), _ptr(f32), _ptr(n32), corpus.d, _ptr(batch.descs_dev), batch.K, batch.win,
+                                          batch.max_nx, batch.max_ny, _ptr(koff), _stream()), "keys16_koff_f32_batch")
+    return koff[:batch.K]
+
+
+def keys16_band_f32(corpus, batch):
+    """(base, slope) of the error band for a float32 corpus: the filter's cross-similarity values are the exact path's bit for
+    bit, so only the root-square (3 u) and the float32 window sum (4 u) separate the two: a purely relative band (9.5 u as
+    for float64 corpora: margin), plus a few denormal steps."""
+    up = 1.0 + 2.0 ** -10
+    band = np.empty((batch.K, 2), dtype=np.float32)
+    band[:, 0] = np.float32(2.0 ** -140)
+    band[:, 1] = np.nextafter(np.float32(2.0 * PLANAR32_BOUND_T * up), np.float32(np.inf))
+    return torch.from_numpy(np.ascontiguousarray(band.reshape(-1))).to(corpus.device)
 
 
 def crp_keys16(corpus, batch, xp32, koff, out=None):
@@ -795,11 +837,45 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             for k in want:
                 out[k][part] = res[k]
         return out
+    if corpus.dtype == np.float32 and approx32 is not False and planar32_default():
+        # the float32 filter cannot tell the cells of a row apart when one song of the pair has (next to) no variation
+        # against the other's scale -- a silent or constant track: every row or column is then refined exactly, cell by cell,
+        # which costs far more than the plain chain: such pairs take the plain float32-input chain
+        v = song_variation(corpus)
+        a, b = v[pairs[:, 0]], v[pairs[:, 1]]
+        flat = np.minimum(a, b) < 2.0 ** -20 * np.maximum(a, b)
+        if flat.any():
+            for part, a32 in ((np.flatnonzero(~flat), approx32), (np.flatnonzero(flat), False)):
+                if len(part):
+                    res = serra09_scores_py(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs, a32)
+                    for k in want:
+                        out[k][part] = res[k]
+            return out
     if batch_pairs is None:
         # ~4096 pairs of 1000-frame songs per launch batch (34 GB of the 288): the one-wave-per-pair alignment kernel
         # needs thousands of pairs in flight
         per_pair = float(max(lens[pairs[:, 0]].max(), lens[pairs[:, 1]].max())) ** 2 * 9.2
         batch_pairs = int(max(1, min(K, (36 << 30) // max(per_pair, 1.0))))
+    # The scores of a batch travel to pinned host memory asynchronously, behind its kernels on the stream, and are read after ONE
+    # synchronisation at the end: the host plans and launches batch after batch while the GPU works (every scratch buffer is
+    # reused in stream order), instead of waiting for each batch's scores before it plans the next.
+    pending = []
+
+    def fetch_later(lo_, n_, denom_, got_):
+        host = {}
+        for kind, t in got_.items():
+            h = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+            h.copy_(t, non_blocking=True)
+            host[kind] = h
+        pending.append((lo_, n_, denom_, host))
+
+    def flush():
+        if pending:
+            torch.cuda.synchronize()
+        while pending:
+            lo_, n_, denom_, host = pending.pop(0)
+            for kind, h in host.items():
+                out[kind][lo_:lo_ + n_] = h.numpy().astype(np.float64) / denom_
     for lo in range(0, K, batch_pairs):
         sel = pairs[lo:lo + batch_pairs]
         batch = PairBatch(corpus.frame_off, sel, m, corpus.device, pitch_align=PLANAR_PITCH_ALIGN)
@@ -837,9 +913,10 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             bits, _ = mask_bits_fused(corpus, batch, kappa, mutual=True, out=bits_buf)
         elif use32 and keys16_default() and keys16_supported(corpus, batch):
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
-            koff = keys16_koff(corpus, batch)
+            koff = keys16_koff_f32(corpus, batch, xp32) if filter32 else keys16_koff(corpus, batch)
+            band = keys16_band_f32(corpus, batch) if filter32 else planar32_band(corpus, batch)
             k16 = crp_keys16(corpus, batch, xp32, koff, out=T.view(torch.int16)[:planar_elems(batch) + 64])
-            bits, work = mask_bits_keys16(k16, planar32_band(corpus, batch), koff, xp32, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
+            bits, work = mask_bits_keys16(k16, band, koff, xp32, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
         elif use32:
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
             keys = crp_planar32(corpus, batch, xp32, out=T.view(torch.int32)[:planar_elems(batch)])
@@ -852,17 +929,18 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
         if planar or bits_path_supported(batch):
             if not planar:
                 bits, work = mask_bits(T, batch, kappa, mutual=True, out=bits_buf, work=work)
+            got = {}
             if "qmax" in want and "dmax" in want:
-                q, d = align_bits_qd(bits, batch, boundary=1)
-                out["qmax"][lo:lo + len(sel)] = q.cpu().numpy().astype(np.float64) / denom
-                out["dmax"][lo:lo + len(sel)] = d.cpu().numpy().astype(np.float64) / denom
+                got["qmax"], got["dmax"] = align_bits_qd(bits, batch, boundary=1)
             elif "qmax" in want:
-                out["qmax"][lo:lo + len(sel)] = align_bits("qmax", bits, batch).cpu().numpy().astype(np.float64) / denom
+                got["qmax"] = align_bits("qmax", bits, batch)
             elif "dmax" in want:
-                out["dmax"][lo:lo + len(sel)] = align_bits("dmax", bits, batch, boundary=1).cpu().numpy().astype(np.float64) / denom
+                got["dmax"] = align_bits("dmax", bits, batch, boundary=1)
             if "swc" in want:
-                out["swc"][lo:lo + len(sel)] = align_bits("swc", bits, batch).cpu().numpy().astype(np.float64) / denom
+                got["swc"] = align_bits("swc", bits, batch)
+            fetch_later(lo, len(sel), denom, got)
             continue
+        flush()
         if fused_align_supported(batch):
             work = thresholds(T, batch, kappa, mutual=True, work=work)
             if "qmax" in want:
@@ -876,6 +954,7 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             out["qmax"][lo:lo + len(sel)] = align("qmax", B, mats).cpu().numpy().astype(np.float64) / denom
         if "dmax" in want:
             out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
+    flush()
     return out
 
 

@@ -431,7 +431,7 @@ def config3_job(tmpdir, alignments=("qmax", "dmax", "swc")):
             alg.similarity(synth.all_pairs(ch.n_songs)[:8192].astype(np.int64))          # warm: device corpus, scratch, float32 copy
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            alg.all_pairwise(symmetric=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             keys = ["chroma_%s" % a for a in alg.alignments]
@@ -663,7 +663,7 @@ def extras_full_job(corpus_h, torch, tmpdir):
         sl = synth.make_corpus(n // 4, 4, n_frames=1000, seed=20260)
         with contextlib.redirect_stdout(io.StringIO()):
             alg = Serra09(sl, shortname="bench_slice", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
-            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            alg.all_pairwise(symmetric=True)
             stats = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=True) for k in ("chroma_qmax", "chroma_dmax")}
         pairs = synth.all_pairs(n)
         same_scores = all(np.array_equal(np.asarray(alg.Ds[k])[pairs[:, 0], pairs[:, 1]], g[k].astype(np.float32))
@@ -682,7 +682,7 @@ def extras_full_job(corpus_h, torch, tmpdir):
         hc = synth.config2_hard()
         with contextlib.redirect_stdout(io.StringIO()):
             alg = Serra09(hc, shortname="bench_hard", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
-            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            alg.all_pairwise(symmetric=True)
             hs = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=False) for k in ("chroma_qmax", "chroma_dmax")}
             hs_gpu = alg.getEvalStatistics("chroma_qmax", verbose=False, write_csv=False, on_gpu=True)
         hp = synth.all_pairs(hc.n_songs)
@@ -697,10 +697,10 @@ def extras_full_job(corpus_h, torch, tmpdir):
         del alg
         with contextlib.redirect_stdout(io.StringIO()):
             alg = Serra09(corpus_h, shortname="bench_full", do_memmaps=False, cachedir=os.path.join(tmpdir, "cache"))
-            alg.all_pairwise(symmetric=True, batch_pairs=65536)          # warm: device corpus, scratch of the final size
+            alg.all_pairwise(symmetric=True)          # warm: device corpus, scratch of the final size
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            alg.all_pairwise(symmetric=True, batch_pairs=65536)
+            alg.all_pairwise(symmetric=True)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             res = {k: alg.getEvalStatistics(k, verbose=False, write_csv=False, on_gpu=True) for k in ("chroma_qmax", "chroma_dmax")}

@@ -313,6 +313,12 @@ int acoss_mask_bits_keys16_batch(const uint16_t *keys16, const float *band, cons
  * exact path's and only the root-square and the float32 window sum separate the two (within the band's slope).  What the keys
  * and recomputed float32 values cannot decide is finished with the exact float32-input arithmetic
  * (sum over the window of (double)(sqrtf(max(c, 0))^2)): masks identical to acoss_crp_batch_f32 + acoss_mask_bits_batch. */
+/* koff[pair] for a float32 corpus.  Such a corpus is its own filter operand (not centred), and features with a common offset --
+ * real MFCC -- have raw norm sums far above every distance; but |x - y|^2 <= 2 (|x - m|^2 + |y - m|^2) for any m, so the key
+ * range hangs on squared norms centred PER PAIR (m = the midpoint of the two songs' mean frames): top = 2 (Wx + Wy), koff = the
+ * pattern of top 2^-7.  One block per pair.  Arguments as acoss_crp_keys16_batch's. */
+int acoss_keys16_koff_f32_batch(const float *xp, const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K,
+                                int win, int max_nx, int max_ny, uint32_t *koff, void *stream);
 int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, const uint32_t *koff, const float *xp,
                                      const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K, int win,
                                      int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,

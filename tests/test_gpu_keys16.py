@@ -24,8 +24,10 @@ def _cells(d):
 
 def _chain(eng, corpus, batch):
     xp32 = eng.pack_x32(corpus, batch)
-    koff = eng.keys16_koff(corpus, batch)
-    band = eng.planar32_band(corpus, batch)
+    if corpus.dtype == np.float32:
+        koff, band = eng.keys16_koff_f32(corpus, batch, xp32), eng.keys16_band_f32(corpus, batch)
+    else:
+        koff, band = eng.keys16_koff(corpus, batch), eng.planar32_band(corpus, batch)
     return xp32, koff, band, eng.crp_keys16(corpus, batch, xp32, koff)
 
 
