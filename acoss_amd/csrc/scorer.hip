@@ -146,9 +146,22 @@ static int plan_batches(const acoss_corpus *c, const int32_t *pairs, int K, int 
             for (int t = 0; t < 2; t++) longest = std::max(longest, c->frame_off[pairs[2 * p + t] + 1] - c->frame_off[pairs[2 * p + t]]);
         int bp = batch_pairs;
         if (bp <= 0) {
-            // ~4096 pairs of 1000-frame songs per launch batch (the one-wave-per-pair alignment kernel wants thousands in flight)
-            const double per_pair = (double)longest * (double)longest * (cls == 3 ? 17.0 : 9.2);
+            // ~4096 pairs of 1000-frame songs per launch batch (the one-wave-per-pair alignment kernels want thousands in flight);
+            // ragged corpora are budgeted by the cells their pairs really have (mean over the class, the caller's order is
+            // arbitrary), plus what every pair costs whatever its size (bit planes, packed x frames, thresholds): up to 8192
+            // pairs = eight alignment waves per SIMD
+            double cells = 0.0;
+            for (int p : v)
+                cells += (double)(c->frame_off[pairs[2 * p] + 1] - c->frame_off[pairs[2 * p]]) * (double)(c->frame_off[pairs[2 * p + 1] + 1] - c->frame_off[pairs[2 * p + 1]]);
+            cells /= (double)v.size();
+            const double per_pair = cls == 3 ? (double)longest * (double)longest * 17.0
+                                             : std::min((double)longest * (double)longest, 1.15 * cells) * 8.8 + (double)longest * 400.0;
             bp = (int)std::max(1.0, std::min((double)v.size(), (cls == 3 ? 8.0 : 36.0) * 1073741824.0 / std::max(per_pair, 1.0)));
+            if (cls <= 1) bp = std::min(bp, 8192);
+            // the alignment kernels run one wave per pair: a batch of 4203 pairs puts a fifth wave on some of the 1024 SIMDs and
+            // the launch takes as long as 5120 would; whole multiples of 4096 (of 1024 for smaller budgets) leave no such tail
+            if (bp >= 4096 && (int)v.size() > bp) bp -= bp % 4096;
+            else if (bp >= 1024 && (int)v.size() > bp) bp -= bp % 1024;
         }
         for (size_t lo = 0; lo < v.size(); lo += (size_t)bp) {
             BatchPlan b;

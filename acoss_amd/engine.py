@@ -856,6 +856,8 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
         # needs thousands of pairs in flight
         per_pair = float(max(lens[pairs[:, 0]].max(), lens[pairs[:, 1]].max())) ** 2 * 9.2
         batch_pairs = int(max(1, min(K, (36 << 30) // max(per_pair, 1.0))))
+        if batch_pairs >= 4096 and K > batch_pairs:
+            batch_pairs -= batch_pairs % 4096          # whole waves-per-SIMD rounds for the one-wave-per-pair alignment kernels
     # The scores of a batch travel to pinned host memory asynchronously, behind its kernels on the stream, and are read after ONE
     # synchronisation at the end: the host plans and launches batch after batch while the GPU works (every scratch buffer is
     # reused in stream order), instead of waiting for each batch's scores before it plans the next.
