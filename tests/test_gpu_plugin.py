@@ -198,3 +198,19 @@ def test_config3_swc_through_the_plugin(golden, tmp_path):
     assert sorted(Serra09(corpus, shortname="mini_d", do_memmaps=False).similarity_types) == sorted(Serra09.KEYS)
     with pytest.raises(ValueError):
         Serra09(corpus, shortname="bad", do_memmaps=False, alignments=("qmax", "swc"))
+
+
+def test_all_pairwise_twice_gives_the_same_matrices(tmp_path, monkeypatch):
+    """A second all_pairwise() on the same object starts its matrices from zero again: `Ds += Ds.T` (CoverAlgorithm.py:180-182)
+    must not add the new upper triangle to the previous call's lower one (round 3's advisor finding)."""
+    from acoss_amd import synth
+    from acoss_amd.Serra09 import Serra09
+    monkeypatch.chdir(tmp_path)
+    corpus = synth.make_corpus(3, 2, seed=21, lengths=lambda r: r.integers(80, 160))
+    alg = Serra09(corpus, shortname="twice", do_memmaps=False, cachedir=str(tmp_path / "cache"))
+    alg.all_pairwise(symmetric=True)
+    first = {k: np.array(v) for k, v in alg.Ds.items()}
+    alg.all_pairwise(symmetric=True)
+    for k in first:
+        assert np.array_equal(np.asarray(alg.Ds[k]), first[k]), k
+    assert np.max(first["chroma_qmax"]) > 0 and np.array_equal(first["chroma_qmax"], first["chroma_qmax"].T)
