@@ -34,7 +34,10 @@ namespace acoss {
 constexpr unsigned K16_FINE = 16384u;                 // first key of the fine region; K16_FINE_BIAS = (4 << 14) - K16_FINE ... 49152
 constexpr unsigned K16_FINE_BIAS = 49152u;
 constexpr unsigned K16_MAX = 0xFFFEu, K16_PAD = 0xFFFFu;
-constexpr int K16_SHIFT0 = 4, K16_SHIFT_MAX = 10;     // histogram bin widths (log2, in keys): the 32-bit selection's window / 2^9
+#ifndef K16_SHIFT0_V
+#define K16_SHIFT0_V 4
+#endif
+constexpr int K16_SHIFT0 = K16_SHIFT0_V, K16_SHIFT_MAX = 10;     // histogram bin widths (log2, in keys): the 32-bit selection's window / 2^9
 constexpr int K16_SCRATCH = 256;                      // words of wave-private LDS behind the histogram (slow path): positions,
                                                       // C values, float32 keys, extra mask bits (the last quarter: zero between uses)
 constexpr int K16_HIST_WORDS = HIST256_BINS + 64 + K16_SCRATCH;
@@ -65,8 +68,45 @@ __device__ inline void key16_bits_range(unsigned key, unsigned koff, unsigned &f
 #define K16_STAT(ctr, slot) do { } while (0)
 #endif
 
+// Development (probes build, K16Ctx.flags & 4): where a wave's cycles go, phase by phase -- s_memtime at the phase boundaries (after
+// the waits the code has there anyway), summed per wave and added to stats[4 + phase] in units of 64 cycles when the wave ends (one block in 64 reports; stats[11] = the rows
+// or columns those waves handled).
+struct K16Probe {
+#ifdef ACOSS_PROBES
+    uint64_t last;
+    uint32_t acc[8];
+    bool on;
+    __device__ inline void start(bool enable)
+    {
+        on = enable;
+        for (int s = 0; s < 8; s++) acc[s] = 0u;
+        last = on ? __builtin_readcyclecounter() : 0u;
+    }
+    __device__ inline void lap(int phase)
+    {
+        if (!on) return;
+        const uint64_t t = __builtin_readcyclecounter();
+        acc[phase] += (uint32_t)(t - last);
+        last = t;
+    }
+    __device__ inline void count() { if (on) acc[7]++; }            // one more row / column (phase 7 = their number)
+    __device__ inline void flush(int *stats, int lane)
+    {
+        // (one block in 64 reports: a million atomics on one line would take longer than the kernel)
+        if (!on || stats == nullptr || lane != 0 || (blockIdx.x & 63) != 0) return;
+        for (int s = 0; s < 7; s++) atomicAdd(stats + 4 + s, (int)(acc[s] >> 6));
+        atomicAdd(stats + 4 + 7, (int)acc[7]);
+    }
+#else
+    __device__ inline void start(bool) {}
+    __device__ inline void lap(int) {}
+    __device__ inline void count() {}
+    __device__ inline void flush(int *, int) {}
+#endif
+};
+
 struct K16Ctx {
-    int flags;              // development (probes build): 1 = treat every row as decided by its 16-bit keys (timing only)
+    int flags;              // development (probes build): 1 = every row decided by its 16-bit keys (timing only), 4 = K16Probe
     int *stats;             // development counters (probes build): [1] float32 recomputes, [2] full-range passes, [3] finer passes
     const float *xp;        // packed x frames of the batch (pack_x32): [pair][max_nx][16]
     int max_nx;
@@ -139,6 +179,23 @@ __device__ inline void k16_reach(unsigned th, unsigned koff, bool adjacent_ok, c
     h_hi = th >= K16_MAX ? K16_MAX : key16_of_bits(__float_as_uint(h) + 1u, koff);
 }
 
+// a packed constant the optimiser cannot see through: min(x, 1) on packed halves stays ONE v_pk_min_u16 (with a visible 1 it
+// becomes two compares, two selects and a permute per register), x * 4 + b one v_pk_mad_u16
+__device__ inline u16x2 k16_opaque(unsigned packed)
+{
+    asm("" : "+v"(packed));
+    return k16_from_u32(packed);
+}
+__device__ inline u16x2 k16_opaque_ones() { return k16_opaque(0x00010001u); }
+
+// LDS by byte offset (wave-private histogram words): the offset of a __shared__ word, and += 1 at an offset
+typedef __attribute__((address_space(3))) unsigned k16_lds_word;
+__device__ inline unsigned k16_lds_offset(unsigned *p) { return (unsigned)(uintptr_t)(k16_lds_word *)p; }
+__device__ inline void k16_lds_add1(unsigned byte_offset)
+{
+    __hip_atomic_fetch_add((k16_lds_word *)(uintptr_t)byte_offset, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
 struct Sel16 {
     unsigned th;        // the k-th smallest key
     int rk;             // the k-th smallest is the rk-th (1-based) among the keys equal to th
@@ -151,31 +208,115 @@ struct Sel16 {
     bool ok;
 };
 
+// ---- the pieces of wave_select_k16 ---------------------------------------------------------------------------------------------
+// One histogram pass: bin the wave's keys (bin = (key -sat lo0) >> shift, everything from bin 256 up in a per-lane spill word),
+// find the bin of the k-th smallest.  lo0 wave-uniform.  hit = false: the k-th smallest lies above the 256 bins.
+struct K16Pass {
+    int r;              // the k-th smallest is the r-th of its bin
+    int cstar;          // keys in that bin
+    unsigned bstar;     // the bin
+    bool hit;
+};
+
+__device__ inline K16Pass k16_hist_pass(const u16x2 (&h)[8], int k, unsigned *hist, unsigned hist_lds, int lane, unsigned lo0, int shift)
+{
+    // bins of the 16 keys, stage by stage over the registers (independent neighbours: no wait states between the packed
+    // instructions), then their LDS byte addresses in packed form too: hist sits below 64 KB, 4 * bin + base fits 16 bits
+    const u16x2 lo_pk = k16_splat(lo0), sh_pk = k16_splat((unsigned)shift), spill_pk = k16_splat((unsigned)(HIST256_BINS + lane));
+    const u16x2 base_pk = k16_splat(hist_lds), four_pk = k16_opaque(0x00040004u);      // (opaque: one v_pk_mad_u16, not shift + add)
+    u16x2 b[8];
+#pragma unroll
+    for (int v = 0; v < 8; v++) b[v] = __builtin_elementwise_sub_sat(h[v], lo_pk);
+#pragma unroll
+    for (int v = 0; v < 8; v++) b[v] = b[v] >> sh_pk;
+#pragma unroll
+    for (int v = 0; v < 8; v++) b[v] = __builtin_elementwise_min(b[v], spill_pk);
+#pragma unroll
+    for (int v = 0; v < 8; v++) b[v] = b[v] * four_pk + base_pk;
+#pragma unroll
+    for (int v = 0; v < 8; v++) {
+        const unsigned a2 = k16_to_u32(b[v]);
+        k16_lds_add1(a2 & 0xFFFFu);
+        k16_lds_add1(a2 >> 16);
+    }
+    const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[lane];
+    const int tot = (int)(c4.x + c4.y + c4.z + c4.w);
+    const int incl = wave_scan<OpAdd>(tot, 0);
+    hist256_clear(hist, lane);
+    // The lane whose four bins hold the k-th smallest decodes it by itself, one word for the whole wave to read: with
+    // q_t = k - 1 - (keys before its bin t) the bin is the LAST t with q_t >= 0, so the unsigned minimum over t of
+    // (q_t << 13 | (3 - t) << 11 | c_t) -- negative q_t are huge, equal q_t (an empty bin in front) fall to the later bin --
+    // carries the rank inside the bin (q_t + 1), the bin and its count (<= 1024: 11 bits).
+    const int q0 = k - 1 - (incl - tot), q1 = q0 - (int)c4.x, q2 = q1 - (int)c4.y, q3 = q2 - (int)c4.z;
+    const unsigned e0 = ((unsigned)q0 << 13) + (c4.x + (3u << 11)), e1 = ((unsigned)q1 << 13) + (c4.y + (2u << 11));
+    const unsigned e2 = ((unsigned)q2 << 13) + (c4.z + (1u << 11)), e3 = ((unsigned)q3 << 13) + c4.w;
+    const unsigned code = min(min(e0, e1), min(e2, e3));
+    const uint64_t m1 = __ballot((unsigned)q0 < (unsigned)tot);
+    K16Pass ps;
+    ps.hit = m1 != 0;
+    ps.r = 0; ps.cstar = 0; ps.bstar = 0;
+    if (ps.hit) {
+        const int ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
+        const unsigned cd = (unsigned)__builtin_amdgcn_readlane((int)code, ls);
+        ps.r = (int)(cd >> 13) + 1;
+        ps.cstar = (int)(cd & 0x7FFu);
+        ps.bstar = (unsigned)(4 * ls + 3) - ((cd >> 11) & 3u);
+    }
+    return ps;
+}
+
+// the keys of [binlo, binlo + binw], one per lane: the smallest offset from binlo
+__device__ inline uint64_t k16_bin_keys(const u16x2 (&h)[8], unsigned binlo, unsigned binw, unsigned &ch)
+{
+    const u16x2 bl_pk = k16_splat(binlo);
+    u16x2 mo = k16_splat(0xFFFFu);
+#pragma unroll
+    for (int v = 0; v < 8; v++) mo = __builtin_elementwise_min(mo, h[v] - bl_pk);
+    const unsigned off = min((unsigned)mo.x, (unsigned)mo.y);
+    ch = binlo + off;
+    return __ballot(off <= binw);
+}
+
 // k-th smallest of the wave's 16-bit keys: lane l holds positions 16 l .. 16 l + 15 as eight packed pairs (position
 // 16 l + 2 v in the low half of h[v]); positions past the end hold K16_PAD.  hist: K16_HIST_WORDS words, zero on entry and on
 // return.  Same method as wave_select_hist256_u32: 256 bins around the key predicted by the previous row, bin 0 catches
 // everything below the window (the subtraction saturates), a miss re-bins the whole range, a bin holding two keys of one lane
-// is re-binned finer.  ok = false: cannot happen for 1 <= k <= n.
-__device__ inline Sel16 wave_select_k16(const u16x2 (&h)[8], int k, unsigned *hist, int lane, HistWarm &warm, int *stats = nullptr)
+// is re-binned finer.  The predicted pass that hits is straight-line code (nine rows in ten); everything else is the loop behind
+// it.  ok = false: cannot happen for 1 <= k <= n.
+__device__ inline Sel16 wave_select_k16(const u16x2 (&h)[8], int k, unsigned *hist, int lane, HistWarm &warm, int *stats, K16Probe &pr)
 {
     Sel16 res;
     res.ok = false;
     res.th = 0;
     res.rk = 1;
     res.ceq = 1;
-    enum { PREDICTED, FULL, REFINE };
-    int kind = warm.hi != 0 ? PREDICTED : FULL;
-    unsigned lo0 = 0;
-    int shift = warm.shift;
-    if (kind == PREDICTED) {
-        const unsigned back = (unsigned)(HIST256_BINS / 2 + 1) << shift;
-        lo0 = max(warm.hi, back) - back;
-    }
+    const unsigned hist_lds = k16_lds_offset(hist);
     int r = 0, cstar = 0;
-    unsigned bstar = 0, ch = 0, binlo = 0, binw = 0;
+    unsigned ch = 0, binlo = 0, binw = 0;
     uint64_t any = 0;
-    for (;;) {
-        if (kind == FULL) {
+    // what the loop starts with when the straight path does not finish: a pass over the full range, or a finer one
+    bool full = true, found = false;
+    unsigned lo0 = 0;
+    int shift = 0;
+    if (warm.hi != 0) {
+        shift = warm.shift;
+        const unsigned back = (unsigned)(HIST256_BINS / 2 + 1) << shift;
+        lo0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(max(warm.hi, back) - back));
+        const K16Pass ps = k16_hist_pass(h, k, hist, hist_lds, lane, lo0, shift);
+        pr.lap(1);
+        if (ps.hit && ps.bstar != 0) {
+            r = ps.r;
+            cstar = ps.cstar;
+            binlo = lo0 + (ps.bstar << shift);
+            binw = (1u << shift) - 1u;
+            any = k16_bin_keys(h, binlo, binw, ch);
+            found = __popcll(any) == cstar;
+            full = false;                              // (not found: two keys of one lane in the bin -- finer bins)
+        } else
+            warm.shift = min(warm.shift + 1, K16_SHIFT_MAX);
+    }
+    while (!found) {
+        if (full) {
             K16_STAT(stats, 2);
             u16x2 mn = k16_splat(0xFFFFu), mx1 = k16_splat(0u);
 #pragma unroll
@@ -191,74 +332,37 @@ __device__ inline Sel16 wave_select_k16(const u16x2 (&h)[8], int k, unsigned *hi
             lo0 = mnl;
             const unsigned span = mxl > mnl ? mxl - 1u - mnl : 0u;
             shift = max(0, 32 - (int)__clz(span) - HIST256_LOG2);
+        } else {
+            if (shift == 0) {
+                // equal keys inside one lane: the threshold key is binlo itself; ranks among equals are positions' business
+                res.th = binlo;
+                res.ceq = cstar;
+                res.rk = r;
+                res.binlo = binlo;
+                res.binw = 0;
+                res.ch = ch;
+                res.any = any;
+                res.cstar = cstar;
+                res.ok = true;
+                return res;
+            }
+            K16_STAT(stats, 3);
+            const int fine = max(shift - (HIST256_LOG2 - 1), 0);
+            lo0 = binlo - min(binlo, 1u << fine);
+            // (bins 1 .. 128 cover the old bin when lo0 = binlo - 2^fine; at the bottom of the key range bin 0 shares it)
+            shift = fine;
         }
         lo0 = (unsigned)__builtin_amdgcn_readfirstlane((int)lo0);
-        const u16x2 lo_pk = k16_splat(lo0), sh_pk = k16_splat((unsigned)shift), spill_pk = k16_splat((unsigned)(HIST256_BINS + lane));
-#pragma unroll
-        for (int v = 0; v < 8; v++) {
-            const u16x2 b = __builtin_elementwise_min(__builtin_elementwise_sub_sat(h[v], lo_pk) >> sh_pk, spill_pk);
-            atomicAdd(&hist[(unsigned)b.x], 1u);
-            atomicAdd(&hist[(unsigned)b.y], 1u);
-        }
-        const uint4 c4 = reinterpret_cast<const uint4 *>(hist)[lane];
-        const int tot = (int)(c4.x + c4.y + c4.z + c4.w);
-        const int incl = wave_scan<OpAdd>(tot, 0);
-        hist256_clear(hist, lane);
-        const uint64_t m1 = __ballot((incl - tot < k) & (k <= incl));
-        int ls = 0, ts = 0;
-        if (m1 != 0) {
-            ls = __builtin_amdgcn_readfirstlane(__ffsll((unsigned long long)m1) - 1);
-            r = k - (__builtin_amdgcn_readlane(incl, ls) - __builtin_amdgcn_readlane(tot, ls));
-            const int c0 = __builtin_amdgcn_readlane((int)c4.x, ls), c1 = __builtin_amdgcn_readlane((int)c4.y, ls);
-            const int c2 = __builtin_amdgcn_readlane((int)c4.z, ls), c3 = __builtin_amdgcn_readlane((int)c4.w, ls);
-            cstar = c0;
-            if (r > c0) {
-                r -= c0; ts = 1; cstar = c1;
-                if (r > c1) {
-                    r -= c1; ts = 2; cstar = c2;
-                    if (r > c2) { r -= c2; ts = 3; cstar = c3; }
-                }
-            }
-        }
-        bstar = (unsigned)(4 * ls + ts);
-        if (m1 == 0 || (kind == PREDICTED && bstar == 0)) {
-            if (kind != PREDICTED) return res;
-            warm.shift = min(warm.shift + 1, K16_SHIFT_MAX);
-            kind = FULL;
-            continue;
-        }
-        // the keys of bin bstar, one per lane: the smallest offset from the bin's first key
-        binlo = lo0 + (bstar << shift);
+        const K16Pass ps = k16_hist_pass(h, k, hist, hist_lds, lane, lo0, shift);
+        if (!ps.hit) return res;
+        r = ps.r;
+        cstar = ps.cstar;
+        binlo = lo0 + (ps.bstar << shift);
         binw = (1u << shift) - 1u;
-        if (kind != FULL && bstar == 0) { binlo = 0; binw = lo0 + binw; }        // (REFINE: bin 0 = everything below bin 1)
-        const u16x2 bl_pk = k16_splat(binlo);
-        u16x2 mo = k16_splat(0xFFFFu);
-#pragma unroll
-        for (int v = 0; v < 8; v++) mo = __builtin_elementwise_min(mo, h[v] - bl_pk);
-        const unsigned off = min((unsigned)mo.x, (unsigned)mo.y);
-        const bool has = off <= binw;
-        ch = binlo + off;
-        any = __ballot(has);
-        if (__popcll(any) == cstar) break;
-        if (shift == 0) {
-            // equal keys inside one lane: the threshold key is binlo itself; ranks among equals are positions' business
-            res.th = binlo;
-            res.ceq = cstar;
-            res.rk = r;
-            res.binlo = binlo;
-            res.binw = 0;
-            res.ch = ch;
-            res.any = any;
-            res.cstar = cstar;
-            res.ok = true;
-            return res;
-        }
-        K16_STAT(stats, 3);
-        const int fine = max(shift - (HIST256_LOG2 - 1), 0);
-        lo0 = binlo - min(binlo, 1u << fine);
-        // (bins 1 .. 128 cover the old bin when lo0 = binlo - 2^fine; at the bottom of the key range bin 0 shares it)
-        shift = fine;
-        kind = REFINE;
+        if (!full && ps.bstar == 0) { binlo = 0; binw = lo0 + binw; }        // (finer pass: bin 0 = everything below bin 1)
+        any = k16_bin_keys(h, binlo, binw, ch);
+        found = __popcll(any) == cstar;
+        full = false;
     }
     const bool mine = (any >> lane) & 1;
     int less = 0, equal = 1;
@@ -287,32 +391,33 @@ __device__ inline Sel16 wave_select_k16(const u16x2 (&h)[8], int k, unsigned *hi
     return res;
 }
 
+// the 0 / 1 flags of a lane's eight registers (low half: position 2 v, high half: position 2 v + 1) -> its 16 mask bits
+__device__ inline unsigned k16_gather_flags(const u16x2 (&f)[8])
+{
+    unsigned acc = k16_to_u32(f[0]);
+#pragma unroll
+    for (int v = 1; v < 8; v++) acc |= k16_to_u32(f[v]) << (2 * v);
+    return (acc | (acc >> 15)) & 0xFFFFu;
+}
+
 // bit t of the result = (key of position 16 l + t) <= thr   (thr < K16_PAD, so padding is never set)
 __device__ inline unsigned k16_bits_le(const u16x2 (&h)[8], unsigned thr)
 {
-    const u16x2 t_pk = k16_splat(thr), one = k16_splat(1u);
-    unsigned acc = 0;
+    const u16x2 t1_pk = k16_splat(thr + 1u), one = k16_opaque_ones();
+    u16x2 f[8];
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const unsigned gt = k16_to_u32(__builtin_elementwise_min(__builtin_elementwise_sub_sat(h[v], t_pk), one));   // 1 per half: key > thr
-        acc |= gt << (2 * v);
-    }
-    const unsigned notsel = (acc | (acc >> 15)) & 0xFFFFu;
-    return ~notsel & 0xFFFFu;
+    for (int v = 0; v < 8; v++) f[v] = __builtin_elementwise_min(__builtin_elementwise_sub_sat(t1_pk, h[v]), one);    // thr + 1 -sat key > 0
+    return k16_gather_flags(f);
 }
 
-// bit t = key of position 16 l + t lies in [lo, hi]
+// bit t = key of position 16 l + t lies in [lo, hi]   (hi < K16_PAD)
 __device__ inline unsigned k16_bits_in(const u16x2 (&h)[8], unsigned lo, unsigned hi)
 {
-    const u16x2 lo_pk = k16_splat(lo), w_pk = k16_splat(hi - lo), one = k16_splat(1u);
-    unsigned acc = 0;
+    const u16x2 lo_pk = k16_splat(lo), w1_pk = k16_splat(hi - lo + 1u), one = k16_opaque_ones();
+    u16x2 f[8];
 #pragma unroll
-    for (int v = 0; v < 8; v++) {
-        const unsigned out = k16_to_u32(__builtin_elementwise_min(__builtin_elementwise_sub_sat(h[v] - lo_pk, w_pk), one));
-        acc |= out << (2 * v);
-    }
-    const unsigned notin = (acc | (acc >> 15)) & 0xFFFFu;
-    return ~notin & 0xFFFFu;
+    for (int v = 0; v < 8; v++) f[v] = __builtin_elementwise_min(__builtin_elementwise_sub_sat(w1_pk, h[v] - lo_pk), one);
+    return k16_gather_flags(f);
 }
 
 enum { K16_DECIDED = 0, K16_HANDOVER = 1 };

@@ -74,24 +74,33 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
     const unsigned koff = cx.koff[p];
     const float *pair_band = w.band + 2 * p;
     const bool adjacent_ok = k16_reach_adjacent_ok(koff, pair_band);
-    // lane l reads bytes [32 l, 32 l + 32) of the row; lanes past the end read a block of padding keys instead
+    // lane l reads bytes [32 l, 32 l + 32) of the row; lanes past the end read a block of padding keys instead (a per-lane
+    // pointer and step: nothing about the addresses is recomputed per row)
     const int n_lanes = (N + 15) >> 4;
-    const bool tail = (N & 15) != 0;            // wave-uniform
-    const uint16_t *base = keys + ds.crp_off + 16 * lane;
+    // the lane that straddles the end of a row finds K16_PAD behind it: acoss_crp_keys16_batch pads every row to a multiple of 16
+    // columns (strip32_kernels.hip) -- unless the pitch leaves no room for that
+    const bool tail = (N & 15) != 0 && ds.crp_pitch < ((N + 15) & ~15);            // wave-uniform
     const bool inside = lane < n_lanes;
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    auto row_ptr = [&](int i) {
-        return inside ? reinterpret_cast<const u32x4v *>(base + (int64_t)i * ds.crp_pitch) : reinterpret_cast<const u32x4v *>(k16_pad_block);
-    };
-    u32x4v na = __builtin_nontemporal_load(row_ptr(r0)), nb = __builtin_nontemporal_load(row_ptr(r0) + 1);
+    const char *rp = inside ? reinterpret_cast<const char *>(keys + ds.crp_off + 16 * lane + (int64_t)r0 * ds.crp_pitch)
+                            : reinterpret_cast<const char *>(k16_pad_block);
+    const int64_t rstep = inside ? 2 * (int64_t)ds.crp_pitch : 0;
+    u32x4v na = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp)), nb = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp) + 1);
     // the row's 16 mask bits per lane leave through a raw buffer store: wave-uniform row offset + a constant lane offset
     const __amdgpu_buffer_rsrc_t brsrc = __builtin_amdgcn_make_buffer_rsrc(w.row_bits + ((int64_t)p * w.max_m) * 16, 0, M * 128, 0x00020000);
+    int cut = 0;                                 // lane t: row_cut of row r0 + t (rpw <= K16_ROWS_PER_WAVE <= 64), stored once
+    K16Probe pr;                                 // phases: 0 waiting for the row, 1 histogram pass, 2 rest of the selection, 3 decision, 4 stores
+    pr.start((cx.flags & 4) != 0);
     for (int i = r0; i < r1; i++) {
+#ifdef ACOSS_PROBES
+        if (cx.flags & 4) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); pr.lap(0); }
+#endif
         u16x2 h[8] = {k16_from_u32(na.x), k16_from_u32(na.y), k16_from_u32(na.z), k16_from_u32(na.w),
                       k16_from_u32(nb.x), k16_from_u32(nb.y), k16_from_u32(nb.z), k16_from_u32(nb.w)};
         if (i + 1 < r1) {
-            na = __builtin_nontemporal_load(row_ptr(i + 1));
-            nb = __builtin_nontemporal_load(row_ptr(i + 1) + 1);
+            rp += rstep;
+            na = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp));
+            nb = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp) + 1);
         }
         if (tail) k16_pad_tail(h, N, lane);
         unsigned sel = 0;
@@ -101,22 +110,26 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
             const int nv = N - 16 * lane;
             sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
         } else {
-            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
+            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats, pr);
+            pr.lap(2);
             state = s.ok ? k16_decide<D, 0>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, i, sel) : K16_HANDOVER;
+            pr.lap(3);
             if (state == K16_HANDOVER) {
                 if (!k16_hand_over(h, w, p, 0, i, s.ok ? s.th : 0u, lane)) {
                     // no room in the side buffer: marked for the strided refinement kernel
-                    if (lane == 0) {
-                        w.row_thr[(int64_t)p * w.max_m + i] = (uint64_t)(s.ok ? s.th : 0u) << 32;
-                        w.row_cut[(int64_t)p * w.max_m + i] = SELECT_UNRESOLVED;
-                    }
+                    if (lane == 0) w.row_thr[(int64_t)p * w.max_m + i] = (uint64_t)(s.ok ? s.th : 0u) << 32;
+                    cut = lane == i - r0 ? SELECT_UNRESOLVED : cut;
                     continue;
                 }
             }
         }
-        if (lane == 0) w.row_cut[(int64_t)p * w.max_m + i] = state == K16_DECIDED ? 0x7fffffff : -3;
+        cut = lane == i - r0 ? (state == K16_DECIDED ? 0x7fffffff : -3) : cut;
         if (state == K16_DECIDED) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)sel, brsrc, 2 * lane, i * 128, 0);
+        pr.lap(4);
+        pr.count();
     }
+    pr.flush(cx.stats, lane);
+    if (lane < r1 - r0) w.row_cut[(int64_t)p * w.max_m + r0 + lane] = cut;
     // a hint for the column kernel, which starts every wave cold: the last threshold key of the pair's first rows (the low
     // word of a slot that only an unresolved column 0 ever uses, and then with a zero low word = no hint)
     if (lane == 0 && r0 == 0 && warm.hi != 0u) reinterpret_cast<unsigned *>(w.col_thr + (int64_t)p * w.max_n)[0] = warm.hi;
@@ -155,6 +168,8 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
     if (j0 >= N) return;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
+    K16Probe pr;                                 // phases: 0 staging, 1 histogram pass, 2 rest of the selection, 3 decision, 4 stores
+    pr.start((cx.flags & 4) != 0);
     u16x2 hc[4][8];
     {
         // thread (c2, rp): columns 4 c2 .. 4 c2 + 3 of the row pair 64 s + rp (rows 128 s + 2 rp, + 1) for s = 0..7; that pair
@@ -214,6 +229,7 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
             }
         }
     }
+    pr.lap(0);
     const int ja = j0 + 4 * wave;
     if (ja >= N) return;
     unsigned *hist = hist_all + wave * K16_HIST_WORDS;
@@ -237,8 +253,10 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
             const int nv = M - 16 * lane;
             sel = nv >= 16 ? 0xFFFFu : (nv <= 0 ? 0u : ((1u << nv) - 1u));
         } else {
-            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats);
+            const Sel16 s = wave_select_k16(h, k, hist, lane, warm, cx.stats, pr);
+            pr.lap(2);
             state = s.ok ? k16_decide<D, 1>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, j, sel) : K16_HANDOVER;
+            pr.lap(3);
             if (state == K16_HANDOVER) {
                 if (!k16_hand_over(h, w, p, 1, j, s.ok ? s.th : 0u, lane)) {
                     if (lane == 0) {
@@ -252,12 +270,15 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
         if (lane == 0) w.col_cut[(int64_t)p * w.max_n + j] = state == K16_DECIDED ? 0x7fffffff : -3;
         // rows 16 l .. 16 l + 15 of column j = quarter (l & 3) of word l >> 2 of the column's bit vector
         if (state == K16_DECIDED) reinterpret_cast<uint16_t *>(w.col_word(p, j, lane >> 2))[lane & 3] = (uint16_t)sel;
+        pr.lap(4);
+        pr.count();
     };
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         if (ja + c < N) column(hc[c], ja + c);
         if (c == 0) warm.shift = K16_SHIFT0;       // neighbouring columns predict each other closely
     }
+    pr.flush(cx.stats, lane);
 }
 
 // ---- refinement ------------------------------------------------------------------------------------------------------------

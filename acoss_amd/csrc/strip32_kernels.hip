@@ -138,6 +138,9 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
         reinterpret_cast<char *>(out) + CELL * ds.crp_off, 0, (int)(CELL * (int64_t)M * ds.crp_pitch), S32_RSRC_WORD3);
     const bool even_layout = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);       // block-uniform: one store per lane pair
     const uint32_t koff = OUT == 1 ? koff_of[p] : 0u;
+    // the 16-bit plane's rows end on a multiple of 16 columns, K16_PAD (0xFFFF) behind the last key: the row selection reads 16
+    // keys per lane and needs no tail handling then (keys16_kernels.hip)
+    const int Npad = min((N + 15) & ~15, ds.crp_pitch);
     const int bw = wave & 1;                 // odd waves sit one column to the right (see above)
     float *const wr = cbuf + (4 * lk) * R32_LD + R32_CARRY + 16 * wave + lr;
     // (LDS byte address of the lane's first diagonal read: cbuf + (7 wave) rows + bw + 2 lane)
@@ -180,8 +183,8 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
                 __builtin_amdgcn_raw_buffer_store_b32(h0 | (h1 << 16), orsrc, 4 * lane, soff, S32_STORE_POLICY);
             } else if (gi < M) {
                 const int col = (t - 1) * R32_CW + 2 * lane;
-                if (col < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h0, orsrc, 4 * lane, soff, S32_STORE_POLICY);
-                if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)h1, orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
+                if (col < Npad) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(col < N ? h0 : 0xFFFFu), orsrc, 4 * lane, soff, S32_STORE_POLICY);
+                if (col + 1 < Npad) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(col + 1 < N ? h1 : 0xFFFFu), orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
             }
         } else if (FAST) {
             __builtin_amdgcn_raw_buffer_store_b64((u32x2s_t){r0, r1}, orsrc, 8 * lane, soff, S32_STORE_POLICY);
@@ -226,8 +229,8 @@ __global__ __launch_bounds__(512, R32_WPS) void crp_rows32_kernel(const float *_
             __builtin_amdgcn_raw_buffer_store_b32(r, orsrc, 4 * lane, soff, S32_STORE_POLICY);
         } else if (gi < M) {
             const int col = (t - 1) * R32_CW + 2 * lane;
-            if (col < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(r & 0xFFFFu), orsrc, 4 * lane, soff, S32_STORE_POLICY);
-            if (col + 1 < N) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(r >> 16), orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
+            if (col < Npad) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(col < N ? (r & 0xFFFFu) : 0xFFFFu), orsrc, 4 * lane, soff, S32_STORE_POLICY);
+            if (col + 1 < Npad) __builtin_amdgcn_raw_buffer_store_b16((unsigned short)(col + 1 < N ? (r >> 16) : 0xFFFFu), orsrc, 4 * lane + 2, soff, S32_STORE_POLICY);
         }
     };
     const bool fast_band = even_layout && (R0 + R32_BR <= M);      // block-uniform
