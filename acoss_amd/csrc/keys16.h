@@ -16,13 +16,13 @@
 // and pair instead of 12).
 //
 // What 16 bits cannot decide, in order of cost:
-//  1. nothing else within the key range that the float32 error band of the winner can reach (87 % of the rows of the
+//  1. nothing else within the key range that the float32 error band of the winner can reach (92 % of the rows of the
 //     benchmark corpus): the masks follow from key16 <= threshold alone;
 //  2. otherwise the few cells in that range (two or three) get their float32 value RECOMPUTED from the features by the
 //     selecting wave, one cell per lane, with the strip kernel's arithmetic bit for bit (an FMA chain over the bins, the nine
 //     terms added by window_sum9(): tests/test_gpu_fast_path.py pins the matrix-core form against exactly this chain) -- the
 //     full 32-bit keys of those cells then decide as the 32-bit selection does;
-//  3. if the winner is still not alone in its error band (2 %), or the threshold clamps: the row's keys go to the side buffer
+//  3. if the winner is still not alone in its error band (0.5 %), or the threshold clamps: the row's keys go to the side buffer
 //     and select_fix_side16_kernel finishes it in float64 (exact values of every cell in the reachable range).
 // Masks are identical to the float64 path's in every case.
 #pragma once

@@ -292,7 +292,10 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
  * (W_pair = the largest window sum of squared norms of song x + that of song y, i.e. base / (2 * (d + 4.5) * 2^-24) of `band`; the kernels check
  * per pair that `band` and `koff` agree in this sense and fall back to the float evaluation of the reach where they do not; no
  * windowed sum exceeds 2 W_pair): 14 mantissa bits over the three octaves below 2 W_pair, 12 over the four below those, one
- * monotone map; same element indexing as the uint32 matrix (element = 2 bytes).
+ * monotone map; same element indexing as the uint32 matrix (element = 2 bytes).  Behind the last key of a row the kernel writes
+ * 0xFFFF up to the next multiple of 16 columns (as far as crp_pitch has room: acoss_plan_pairs with pitch_align a multiple of
+ * 16 always has): the row selection reads 16 keys per lane and takes such rows without any tail handling; a plane whose pitch
+ * is tighter is still selected correctly (the kernel masks the tail itself then).
  * acoss_mask_bits_keys16_batch selects on those keys; where the winner's error band can reach another key it recomputes
  * the float32 values of the few cells involved from xp / f32 / n32 (the operands acoss_crp_keys16_batch was given, same
  * descriptors) with the strip kernel's arithmetic, and what float32 cannot decide is finished exactly in float64 from

@@ -70,6 +70,12 @@ def test_key_plane_is_the_quantised_float32_matrix(eng, golden):
             kp = np.maximum(k32[idx] - ko[p], 0)
             want = np.minimum(np.maximum(kp >> 11, np.maximum((kp >> 9) - 49152, 0)), 0xFFFE)
             assert np.array_equal(k16[idx], want), (align, p)
+            # behind the last key of a row: 0xFFFF up to the next multiple of 16 columns (where the pitch has room)
+            d = batch.descs[p]
+            pitch, pad_to = int(d["crp_pitch"]), min((N + 15) & ~15, int(d["crp_pitch"]))
+            if pad_to > N:
+                rows = int(d["crp_off"]) + np.arange(M)[:, None] * pitch + np.arange(N, pad_to)[None, :]
+                assert (k16[rows] == 0xFFFF).all(), (align, p)
             W2 = 2.0 * (w[batch.descs["song_x"][p]] + w[batch.descs["song_y"][p]])
             top = np.array([ko[p] + (7 << 23)], dtype=np.uint32).view(np.float32)[0]
             assert W2 <= top <= W2 * (1 + 2.0 ** -22)
