@@ -12,6 +12,8 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 
 #define REP8(X) X(0) X(1) X(2) X(3) X(4) X(5) X(6) X(7)
 #define BODY(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X) REP8(X)
+#define VADD(N) "v_add_u32 %[r" #N "], %[r" #N "], %[a]\n"
+#define SADD(N) "s_add_u32 s2" #N ", s2" #N ", %[s]\n"
 
 #define OPS32 \
     : [r0] "+v"(r0), [r1] "+v"(r1), [r2] "+v"(r2), [r3] "+v"(r3), [r4] "+v"(r4), [r5] "+v"(r5), [r6] "+v"(r6), [r7] "+v"(r7) \
@@ -105,6 +107,30 @@ D64(pk_fma_f32, "v_pk_fma_f32", "%[a], %[b]")
 D64(pk_mul_f32, "v_pk_mul_f32", "%[a]")
 D64(add_f64, "v_add_f64", "%[a]")
 D64(fma_f64, "v_fma_f64", "%[a], %[b]")
+D32(and_b32, "v_and_b32", "%[a]")
+D32(or_b32, "v_or_b32", "%[a]")
+D32(xor_b32, "v_xor_b32", "%[a]")
+D32(min_u32, "v_min_u32", "%[a]")
+D32(sub_u32, "v_sub_u32", "%[a]")
+D32R(lshlrev, "v_lshlrev_b32", "%[b]")
+D32(mul_f32, "v_mul_f32", "%[a]")
+D32(max_f32, "v_max_f32", "%[a]")
+D32(mul_u32_u24, "v_mul_u32_u24", "%[a]")
+D32(bfi, "v_bfi_b32", "%[a], %[b]")
+D32(pk_sub_i16, "v_pk_sub_i16", "%[a]")
+D32(pk_mul_lo_u16, "v_pk_mul_lo_u16", "%[a]")
+D32R(pk_lshlrev_b16, "v_pk_lshlrev_b16", "%[b]")
+D32U(cvt_f32_u32, "v_cvt_f32_u32", "")
+D32U(mbcnt_lo, "v_mbcnt_lo_u32_b32", ", 0")
+// a select on a mask that nothing rewrites (the `cndmask` entry above selects on vcc right behind instructions that clobber it)
+DEF32(cndmask_static, "v_cndmask_b32 %[r0], %[r0], %[a], s[20:21]\n", "v_cndmask_b32 %[r1], %[r1], %[a], s[20:21]\n", "v_cndmask_b32 %[r2], %[r2], %[a], s[20:21]\n",
+      "v_cndmask_b32 %[r3], %[r3], %[a], s[20:21]\n", "v_cndmask_b32 %[r4], %[r4], %[a], s[20:21]\n", "v_cndmask_b32 %[r5], %[r5], %[a], s[20:21]\n",
+      "v_cndmask_b32 %[r6], %[r6], %[a], s[20:21]\n", "v_cndmask_b32 %[r7], %[r7], %[a], s[20:21]\n")
+// eight s_nop 0 / eight s_waitcnt that never wait, between nothing: what an issued no-op costs
+DEF32(s_nop0, "s_nop 0\n", "s_nop 0\n", "s_nop 0\n", "s_nop 0\n", "s_nop 0\n", "s_nop 0\n", "s_nop 0\n", "s_nop 0\n")
+// one vector add + one s_nop 0 / + one scalar add: does the other instruction take an issue slot of the SIMD?
+DEF32(valu_nop_mix, "v_add_u32 %[r0], %[r0], %[a]\n", "s_nop 0\n", "v_add_u32 %[r2], %[r2], %[a]\n", "s_nop 0\n",
+      "v_add_u32 %[r4], %[r4], %[a]\n", "s_nop 0\n", "v_add_u32 %[r6], %[r6], %[a]\n", "s_nop 0\n")
 // v_cmp writing an SGPR pair + dependent cndmask would serialise; a lone compare into vcc
 DEF32(cmp_lt_u32, "v_cmp_lt_u32 vcc, %[r0], %[a]\n", "v_cmp_lt_u32 vcc, %[r1], %[a]\n", "v_cmp_lt_u32 vcc, %[r2], %[a]\n", "v_cmp_lt_u32 vcc, %[r3], %[a]\n",
       "v_cmp_lt_u32 vcc, %[r4], %[a]\n", "v_cmp_lt_u32 vcc, %[r5], %[a]\n", "v_cmp_lt_u32 vcc, %[r6], %[a]\n", "v_cmp_lt_u32 vcc, %[r7], %[a]\n")
@@ -117,6 +143,27 @@ DEF32(salu_bcnt64, "s_bcnt1_i32_b64 s20, vcc\n", "s_bcnt1_i32_b64 s21, vcc\n", "
 // half VALU half SALU, interleaved
 DEF32(valu_salu_mix, "v_add_u32 %[r0], %[r0], %[a]\n", "s_add_u32 s20, s20, %[s]\n", "v_add_u32 %[r2], %[r2], %[a]\n", "s_add_u32 s21, s21, %[s]\n",
       "v_add_u32 %[r4], %[r4], %[a]\n", "s_add_u32 s22, s22, %[s]\n", "v_add_u32 %[r6], %[r6], %[a]\n", "s_add_u32 s23, s23, %[s]\n")
+
+// waves 0 and 2 of a block run the vector-add stream, waves 1 and 3 the scalar-add stream: do streams of different waves share the
+// SIMD's issue?  (a block's four waves sit on the four SIMDs; with 2+ blocks per CU every SIMD holds both kinds)
+__global__ __launch_bounds__(256) void k_split_valu_salu(const unsigned *in, unsigned *out, long long *cyc, int trips)
+{
+    unsigned r0 = in[threadIdx.x], r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3, r4 = r0 + 4, r5 = r0 + 5, r6 = r0 + 6, r7 = r0 + 7;
+    unsigned a = in[64 + (threadIdx.x & 63)] | 1u, b = in[128 + (threadIdx.x & 63)] & 15u;
+    unsigned sv = __builtin_amdgcn_readfirstlane(in[3]);
+    const bool vec = (((threadIdx.x >> 6) + blockIdx.x) & 1) == 0;          // alternate by block too: every SIMD gets both kinds
+    const long long t0 = __builtin_readcyclecounter();
+    if (vec) {
+        for (int it = 0; it < trips; it++)
+            asm volatile(BODY(VADD) OPS32);
+    } else {
+        for (int it = 0; it < trips; it++)
+            asm volatile(BODY(SADD) OPS32);
+    }
+    const long long t1 = __builtin_readcyclecounter();
+    if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + r4 + r5 + r6 + r7;
+}
 
 // LDS: bpermute and atomics (own kernels: need shared memory)
 template <int MODE>
@@ -184,7 +231,9 @@ int main()
         E(alignbit), E(lshrrev), E(mad_u24), E(mul_lo), E(cndmask), E(mov), E(mov_dpp_shr1), E(mov_dpp_rowshr), E(add_dpp), E(fma_f32), E(add_f32),
         E(pk_add_u16), E(pk_sub_u16_clamp), E(pk_max_u16), E(pk_min_u16), E(pk_lshrrev_b16), E(pk_mad_u16), E(cvt_pk_u16_u32), E(mad_u16), E(add_u16),
         E(sad_u16), E(sad_u8), E(dot2_u32_u16), E(dot4_u32_u8), E(pk_add_f32), E(pk_fma_f32), E(pk_mul_f32), E(add_f64), E(fma_f64), E(cmp_lt_u32),
-        E(readlane), E(salu_add), E(salu_bcnt64), E(valu_salu_mix),
+        E(readlane), E(salu_add), E(salu_bcnt64), E(valu_salu_mix), E(and_b32), E(or_b32), E(xor_b32), E(min_u32), E(sub_u32), E(lshlrev),
+        E(mul_f32), E(max_f32), E(mul_u32_u24), E(bfi), E(pk_sub_i16), E(pk_mul_lo_u16), E(pk_lshlrev_b16), E(cvt_f32_u32), E(mbcnt_lo),
+        E(cndmask_static), E(s_nop0), E(valu_nop_mix), E(split_valu_salu),
         {"ds_bpermute", k_lds<0>}, {"ds_add_u32 own word", k_lds<1>}, {"ds_add_u32 256 random bins", k_lds<2>}, {"ds_add_u32 one address", k_lds<3>},
         {"ds_add_u32 8 lanes one address", k_lds<4>}, {"ds_add_rtn_u32 own word", k_lds<5>}, {"ds_read_b32", k_lds<6>}, {"ds_write_b32", k_lds<7>},
     };
