@@ -1,12 +1,12 @@
 import sys, os, time
 import numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth
 rng = np.random.default_rng(1)
 S = 220
 songs = []
 for s_ in range(S):
-    n = int(rng.integers(60, 1033))
+    n = int(os.environ.get("PROBE_FRAMES", 0)) or int(rng.integers(60, 1033))
     songs.append(np.cumsum(rng.standard_normal((n, 13)) * rng.uniform(0.2, 3.0), axis=0).astype(np.float32))
 feats = np.concatenate(songs); off = np.cumsum([0] + [len(s) for s in songs]).astype(np.int64)
 corpus = engine.DeviceCorpus(feats, off)
