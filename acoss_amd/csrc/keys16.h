@@ -265,7 +265,9 @@ __device__ inline K16Pass k16_hist_pass(const u16x2 (&h)[8], int k, unsigned *hi
     return ps;
 }
 
-// the keys of [binlo, binlo + binw], one per lane: the smallest offset from binlo
+// the keys of [binlo, binlo + binw], one per lane: the smallest offset from binlo.  (Offsets are taken modulo 2^16: a key below
+// binlo wraps to 2^16 - (binlo - key), which a bin that reaches past the top of the key range could mistake for one of its own;
+// the limit stops at key 0xFFFF.)
 __device__ inline uint64_t k16_bin_keys(const u16x2 (&h)[8], unsigned binlo, unsigned binw, unsigned &ch)
 {
     const u16x2 bl_pk = k16_splat(binlo);
@@ -274,7 +276,7 @@ __device__ inline uint64_t k16_bin_keys(const u16x2 (&h)[8], unsigned binlo, uns
     for (int v = 0; v < 8; v++) mo = __builtin_elementwise_min(mo, h[v] - bl_pk);
     const unsigned off = min((unsigned)mo.x, (unsigned)mo.y);
     ch = binlo + off;
-    return __ballot(off <= binw);
+    return __ballot(off <= min(binw, 0xFFFFu - binlo));
 }
 
 // k-th smallest of the wave's 16-bit keys: lane l holds positions 16 l .. 16 l + 15 as eight packed pairs (position
