@@ -102,7 +102,13 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
             na = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp));
             nb = __builtin_nontemporal_load(reinterpret_cast<const u32x4v *>(rp) + 1);
         }
-        if (tail) k16_pad_tail(h, N, lane);
+        if (tail) {
+            // (the lane index behind an opaque move: hipcc would otherwise hoist this rare path's sixteen lane conditions out of the
+            //  row loop into SGPR pairs, and spill other scalars of the loop to make room)
+            int tl = lane;
+            asm volatile("" : "+v"(tl));
+            k16_pad_tail(h, N, tl);
+        }
         unsigned sel = 0;
         int state = K16_DECIDED;
         if (k <= 0) sel = 0u;
