@@ -29,6 +29,7 @@ __device__ inline void k16_pad_tail(u16x2 (&h)[8], int n, int lane)
 }
 
 // the keys a wave could not decide: 2 KB to a side-buffer slot, position order
+template <bool OPAQUE_LANE>
 __device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, int p, int dir, int which, unsigned th, int lane)
 {
     if (w.side_keys == nullptr) return false;
@@ -36,7 +37,11 @@ __device__ inline bool k16_hand_over(const u16x2 (&h)[8], const ThreshWork &w, i
     if (lane == 0) slot = atomicAdd(w.side_counter, 1);
     slot = __builtin_amdgcn_readfirstlane(slot);
     if (slot >= w.side_cap) return false;
-    uint4 *dst = reinterpret_cast<uint4 *>(w.side_keys + (int64_t)slot * 1024) + 2 * lane;
+    // (row kernel: the lane index behind an opaque move -- hipcc would otherwise form this rare path's lane address at kernel entry and
+    //  spill it; in the column kernel the same move makes the allocator spill four key registers on the common path instead: A/B)
+    int hl = lane;
+    if (OPAQUE_LANE) asm volatile("" : "+v"(hl));
+    uint4 *dst = reinterpret_cast<uint4 *>(w.side_keys + (int64_t)slot * 1024) + 2 * hl;
     dst[0] = make_uint4(k16_to_u32(h[0]), k16_to_u32(h[1]), k16_to_u32(h[2]), k16_to_u32(h[3]));
     dst[1] = make_uint4(k16_to_u32(h[4]), k16_to_u32(h[5]), k16_to_u32(h[6]), k16_to_u32(h[7]));
     if (lane == 0) w.side_slots[slot] = make_int4(p, dir, which, (int)th);
@@ -121,7 +126,7 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
             state = s.ok ? k16_decide<D, 0>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, i, sel) : K16_HANDOVER;
             pr.lap(3);
             if (state == K16_HANDOVER) {
-                if (!k16_hand_over(h, w, p, 0, i, s.ok ? s.th : 0u, lane)) {
+                if (!k16_hand_over<true>(h, w, p, 0, i, s.ok ? s.th : 0u, lane)) {
                     // no room in the side buffer: marked for the strided refinement kernel
                     if (lane == 0) w.row_thr[(int64_t)p * w.max_m + i] = (uint64_t)(s.ok ? s.th : 0u) << 32;
                     cut = lane == i - r0 ? SELECT_UNRESOLVED : cut;
@@ -152,6 +157,9 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
 #define K16_COL_WAVES 8                   // waves per block, four columns each
 #endif
 constexpr int K16_COLS = 4 * K16_COL_WAVES;
+#ifndef K16_COL_OPAQUE
+#define K16_COL_OPAQUE 0
+#endif
 #ifndef K16_COL_SEED
 #define K16_COL_SEED 1
 #endif
@@ -264,7 +272,7 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
             state = s.ok ? k16_decide<D, 1>(h, s, k, hist + HIST256_BINS + 64, lane, cx, pair_band, koff, adjacent_ok, ds, p, j, sel) : K16_HANDOVER;
             pr.lap(3);
             if (state == K16_HANDOVER) {
-                if (!k16_hand_over(h, w, p, 1, j, s.ok ? s.th : 0u, lane)) {
+                if (!k16_hand_over<(K16_COL_OPAQUE != 0)>(h, w, p, 1, j, s.ok ? s.th : 0u, lane)) {
                     if (lane == 0) {
                         w.col_thr[(int64_t)p * w.max_n + j] = (uint64_t)(s.ok ? s.th : 0u) << 32;
                         w.col_cut[(int64_t)p * w.max_n + j] = SELECT_UNRESOLVED;
