@@ -18,9 +18,9 @@ OBJ = os.path.join(PKG, "build")
 LIB = os.path.join(PKG, "libacoss_mi355x.so")
 SOURCES = ["capi.hip", "crp_kernels.hip", "fused_kernels.hip", "strip32_kernels.hip", "band_kernels.hip",
            "dp_kernels.hip", "planar_kernels.hip", "keys16_kernels.hip", "eval_kernels.hip", "ftm2d_kernels.hip", "snf_kernels.hip",
-           "scorer.hip", "csm_rows_kernels.hip"]
+           "scorer.hip", "csm_rows_kernels.hip", "radix16_kernels.hip"]
 PROBE_SOURCES = []          # (the store-pattern probes moved to tools/ubench/*.hip: stand-alone programs)
-HEADERS = ["common.h", "wave_ops.h", "kernel_utils.h", "thresh_work.h", "gemm_f64.h", "gemm_f32.h", "planar_select.h", "keys16.h",
+HEADERS = ["common.h", "wave_ops.h", "kernel_utils.h", "thresh_work.h", "gemm_f64.h", "gemm_f32.h", "planar_select.h", "keys16.h", "radix16.h",
            os.path.join("..", "..", "include", "acoss_mi355x.h")]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC",

@@ -1,0 +1,78 @@
+// radix16.h -- workspace of the radix form of the kNN selection on the 16-bit key plane (radix16_kernels.hip, round 5).
+//
+// Every row and column leaves the selection kernels as ONE number and, rarely, one work item:
+//     t1       cells whose key is < t1 are selected                                   (0: none, 0xFFFF: every cell)
+//     item     -1, or the index of an R16Item: the cells of the row / column whose keys lie in the reach of the k-th smallest's
+//              float32 error band (keys16.h: k16_reach) -- positions only, at most R16_CAP of them -- of which the `need`
+//              smallest by EXACT value (position breaks ties) are selected too.  r16_exact_kernel fills `sel`.
+// The mutual mask is then   key < min(t1_row[i], t1_col[j])   (written by the row kernel)   OR-ed with the cells the items select
+// on one side that the other side selects too (r16_apply_kernel).
+// A pair the kernels cannot express this way (more than R16_CAP cells inside the captured key window of a row or column: exact
+// ties -- a threshold outside the window its reach needs -- no room for an item) is FLAGGED and redone by the wave-per-row
+// kernels of keys16_kernels.hip.
+#pragma once
+
+#include "keys16.h"
+
+namespace acoss {
+
+constexpr int R16_CAP = 64;              // cells a row / column may hold inside its captured key window
+constexpr int R16_LS = R16_CAP + 1;      // list stride in LDS words (odd: neighbouring lists start in different banks)
+
+struct __attribute__((aligned(16))) R16Item {
+    int p, dir, which, need;
+    int n;
+    unsigned sel_lo, sel_hi;             // bit m: cell pos[m] is selected (r16_exact_kernel)
+    int reserved;
+    uint16_t pos[R16_CAP];
+};                                        // 160 bytes
+
+struct R16Work {
+    uint16_t *t1_row, *t1_col;           // [K][max_m], [K][max_n]
+    int *item_row, *item_col;
+    int *counters;                       // [0] items asked for, [1] pairs flagged (statistics), [2] pairs in pair_list
+    int *pair_list;                      // [K]: the flagged pairs, compacted (r16_flag_list_kernel)
+    unsigned char *pair_flag;            // [K]
+    R16Item *items;
+    int item_cap;
+    int max_m, max_n;
+};
+
+inline int r16_item_cap(int K, int max_m, int max_n)
+{
+    const double lines = (double)K * (double)(max_m + max_n);
+    const double cap = lines * 0.08 < 4096.0 ? 4096.0 : lines * 0.08;
+    return cap > 8.0e6 ? 8000000 : (int)cap;
+}
+
+inline size_t r16_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+inline size_t r16_work_bytes(int K, int max_m, int max_n)
+{
+    size_t b = 256;
+    b += r16_align((size_t)K * max_m * sizeof(uint16_t)) + r16_align((size_t)K * max_n * sizeof(uint16_t));
+    b += r16_align((size_t)K * max_m * sizeof(int)) + r16_align((size_t)K * max_n * sizeof(int));
+    b += r16_align((size_t)K * sizeof(int)) + r16_align((size_t)K);
+    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(R16Item));
+    return b + 256;
+}
+
+inline R16Work r16_work_layout(void *work, int K, int max_m, int max_n)
+{
+    R16Work w;
+    uintptr_t a = ((uintptr_t)work + 255) & ~(uintptr_t)255;
+    w.counters = (int *)a;                  a += 256;
+    w.t1_row = (uint16_t *)a;               a += r16_align((size_t)K * max_m * sizeof(uint16_t));
+    w.t1_col = (uint16_t *)a;               a += r16_align((size_t)K * max_n * sizeof(uint16_t));
+    w.item_row = (int *)a;                  a += r16_align((size_t)K * max_m * sizeof(int));
+    w.item_col = (int *)a;                  a += r16_align((size_t)K * max_n * sizeof(int));
+    w.pair_list = (int *)a;                 a += r16_align((size_t)K * sizeof(int));
+    w.pair_flag = (unsigned char *)a;       a += r16_align((size_t)K);
+    w.items = (R16Item *)a;
+    w.item_cap = r16_item_cap(K, max_m, max_n);
+    w.max_m = max_m;
+    w.max_n = max_n;
+    return w;
+}
+
+}  // namespace acoss

@@ -326,6 +326,20 @@ int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, 
                                      const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K, int win,
                                      int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
                                      size_t work_bytes, void *stream);
+/* Round 5: the selection of acoss_mask_bits_keys16_batch as a two-pass radix selection with the keys in registers
+ * (csrc/radix16_kernels.hip) -- the form acoss_mask_bits_keys16_batch itself runs; these are its stages, exposed for the
+ * per-kernel measurements of bench.py and the stage tests.  `what` is a bit set: 1 = the column kernel (every column's bound
+ * t1: cells with key < t1 are selected; plus work items for the columns whose k-th smallest has another key inside its float32
+ * error band), 2 = the row kernel (the same per row, then the base bits key < min(t1_row, t1_col) of the mutual mask into
+ * `bits`), 4 = exact float64 values for the work items, their cells OR-ed into `bits`, and the list of pairs that have to
+ * go through the wave-per-row kernels (exact ties).  acoss_radix16_layout: device pointers into `work`
+ * (ptrs[8]: t1_row, t1_col, item_row, item_col, counters, items, pair_flag, pair_list; dims[4]: row stride of the t1 / item
+ * arrays for rows and columns, item capacity, item size).  CRPUtils.py:169-219. */
+size_t acoss_radix16_work_bytes(int K, int max_nx, int max_ny, int win);
+int acoss_radix16_layout(void *work, int K, int max_nx, int max_ny, int win, void **ptrs, int *dims);
+int acoss_radix16_stage(int what, const uint16_t *keys16, const float *band, const uint32_t *koff, const double *feats,
+                        const double *norms, int d, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
+                        double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream);
 /* The product path: get_csm + sliding_csm + csm_to_binary_mutual (CRPUtils.py:67-84, :24-45, :201-219) without any
  * matrix in HBM.  One kernel forms a 24-row band of a pair's windowed sums in float32 on the matrix cores, keeps the
  * band's keys in registers, selects each row's k-th smallest and writes only the row's bit plane; run on (x, y) it
