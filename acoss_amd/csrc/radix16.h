@@ -30,7 +30,10 @@ struct __attribute__((aligned(16))) R16Item {
 struct R16Work {
     uint16_t *t1_row, *t1_col;           // [K][max_m], [K][max_n]
     int *item_row, *item_col;
-    int *counters;                       // [0] items asked for, [1] pairs flagged (statistics), [2] pairs in pair_list
+    int *counters;                       // [0] items beyond the tiles' own slots, [1] lines that flagged their pair (statistics), [2] pairs in pair_list, [3] items in item_list
+    int *item_list;                      // the items of unflagged pairs, compacted (r16_item_list_kernel)
+    int *tile_used;                      // [row tiles of every pair][column tiles of every pair]: items in the tile's R16_TILE_ITEMS slots
+    int static_items;                    // R16_TILE_ITEMS x tiles: item index = R16_TILE_ITEMS * tile + slot; the rest of `items` is asked for one by one
     int *pair_list;                      // [K]: the flagged pairs, compacted (r16_flag_list_kernel)
     unsigned char *pair_flag;            // [K]
     R16Item *items;
@@ -38,38 +41,53 @@ struct R16Work {
     int max_m, max_n;
 };
 
+// Every tile of 64 lines owns R16_TILE_ITEMS item slots (no global atomic on the selection kernels' path; 2.5 of a tile's
+// lines need an item on the benchmark); a tile with more asks for single items behind them: room for 2 % of the lines.
+constexpr int R16_TILE_ITEMS = 8;
+constexpr int R16_TILE_LINES = 64;
+
+inline int r16_tiles(int K, int max_m, int max_n) { return K * ((max_m + R16_TILE_LINES - 1) / R16_TILE_LINES + (max_n + R16_TILE_LINES - 1) / R16_TILE_LINES); }
+
 inline int r16_item_cap(int K, int max_m, int max_n)
 {
     const double lines = (double)K * (double)(max_m + max_n);
-    const double cap = lines * 0.08 < 4096.0 ? 4096.0 : lines * 0.08;
-    return cap > 8.0e6 ? 8000000 : (int)cap;
+    const double cap = (double)R16_TILE_ITEMS * (double)r16_tiles(K, max_m, max_n) + lines * 0.02 + 4096.0;
+    return cap > 4.0e7 ? 40000000 : (int)cap;
 }
 
 inline size_t r16_align(size_t b) { return (b + 255) & ~(size_t)255; }
 
+// ldm / ldn: row strides of the t1 / item arrays (the matrix sizes rounded up to 8)
 inline size_t r16_work_bytes(int K, int max_m, int max_n)
 {
-    size_t b = 256;
-    b += r16_align((size_t)K * max_m * sizeof(uint16_t)) + r16_align((size_t)K * max_n * sizeof(uint16_t));
-    b += r16_align((size_t)K * max_m * sizeof(int)) + r16_align((size_t)K * max_n * sizeof(int));
+    const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
+    size_t b = 512;
+    b += r16_align((size_t)K * ldm * sizeof(uint16_t)) + r16_align((size_t)K * ldn * sizeof(uint16_t));
+    b += r16_align((size_t)K * ldm * sizeof(int)) + r16_align((size_t)K * ldn * sizeof(int));
     b += r16_align((size_t)K * sizeof(int)) + r16_align((size_t)K);
+    b += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
+    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
     b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(R16Item));
     return b + 256;
 }
 
 inline R16Work r16_work_layout(void *work, int K, int max_m, int max_n)
 {
+    const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
     R16Work w;
     uintptr_t a = ((uintptr_t)work + 255) & ~(uintptr_t)255;
     w.counters = (int *)a;                  a += 256;
-    w.t1_row = (uint16_t *)a;               a += r16_align((size_t)K * max_m * sizeof(uint16_t));
-    w.t1_col = (uint16_t *)a;               a += r16_align((size_t)K * max_n * sizeof(uint16_t));
-    w.item_row = (int *)a;                  a += r16_align((size_t)K * max_m * sizeof(int));
-    w.item_col = (int *)a;                  a += r16_align((size_t)K * max_n * sizeof(int));
+    w.t1_row = (uint16_t *)a;               a += r16_align((size_t)K * ldm * sizeof(uint16_t));
+    w.t1_col = (uint16_t *)a;               a += r16_align((size_t)K * ldn * sizeof(uint16_t));
+    w.item_row = (int *)a;                  a += r16_align((size_t)K * ldm * sizeof(int));
+    w.item_col = (int *)a;                  a += r16_align((size_t)K * ldn * sizeof(int));
     w.pair_list = (int *)a;                 a += r16_align((size_t)K * sizeof(int));
     w.pair_flag = (unsigned char *)a;       a += r16_align((size_t)K);
+    w.tile_used = (int *)a;                 a += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
+    w.item_list = (int *)a;                 a += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
     w.items = (R16Item *)a;
     w.item_cap = r16_item_cap(K, max_m, max_n);
+    w.static_items = R16_TILE_ITEMS * r16_tiles(K, max_m, max_n);
     w.max_m = max_m;
     w.max_n = max_n;
     return w;

@@ -35,30 +35,40 @@ __device__ inline void r16_lds_add(unsigned byte_off, unsigned v)
 }
 
 constexpr unsigned R16_XMAX = 257u;      // captured window: x = key - (256 B - 1) in [0, 257]
-constexpr unsigned R16_XNONE = 0x1FFu;
+constexpr int R16_THREADS = 1024;        // sixteen waves per block
+constexpr int R16_LINES = R16_TILE_LINES; // columns (rows) per block
 
-template <int LINES>
+// Line l of a tile has its pass-1 counts in half (DIR ? l & 1 : l >> 5) of word (DIR ? l >> 1 : l & 31) of every histogram bin:
+// a column kernel lane owns two neighbouring columns (one dword of a row), the rows of a row-kernel LDS lane group differ in
+// their low five bits -- either way the lanes of a group add into different banks.
 struct R16Lds {
-    unsigned hist[8192];                 // columns: [bin][32 column pairs], two 16-bit counts per word; rows: [row][bin]
-    unsigned S[32 * LINES];              // sums over groups of eight bins: [group][line]
-    unsigned lists[LINES * R16_LS];      // x | position << 9
-    unsigned cnt[LINES];
-    int lineB[LINES], linecb[LINES];
-    unsigned thx[LINES], cle[LINES], red[LINES], rcnt[LINES];
-    int item[LINES];
-    unsigned t1[LINES];
+    unsigned hist[8192];                       // pass 1: [bin][32 words]; pass 2: every thread's hits [slot][thread]; row kernel, last: the mask bytes
+    unsigned S[32 * R16_LINES];                // decode 1: the counts summed over groups of eight bins, [group][line]; then hcnt[thread]
+    unsigned fine[(R16_XMAX + 1) * 16];        // [x][line >> 2]: byte (line & 3) = the line's keys with that x
+    unsigned sub[16 * R16_LINES];              // [(x - 1) >> 4][line]: the line's keys inside bin B, by sixteens
+    int lineB[R16_LINES], linecb[R16_LINES];
+    unsigned t1[R16_LINES];
+    unsigned dec[R16_LINES], rcnt[R16_LINES];
+    int ditem[R16_LINES];
+    unsigned ovf_n, item_n;
+    uint4 tcol[128];                           // row kernel: the pair's column bounds
 };
+constexpr int R16_SLOTS = 8;                   // hits a thread can hold (x | position << 9 | line << 19 each); further ones go to
+constexpr int R16_OVF = 1024;                  // the block's overflow list: the upper half of S
 
-// ---- decode 1: the high byte of every line's k-th smallest key -------------------------------------------------------------------
-// S holds the line's counts summed over groups of eight bins; lane `line` walks the 32 groups, then the eight bins of its group.
-template <int LINES, typename CountFn>
-__device__ inline void r16_decode1(R16Lds<LINES> &sm, int line, int k, CountFn count_of)
+template <int DIR> __device__ inline int r16_word(int line) { return DIR ? line >> 1 : line & 31; }
+template <int DIR> __device__ inline int r16_half(int line) { return DIR ? line & 1 : line >> 5; }
+
+// ---- decode 1: the high byte of every line's k-th smallest key (lane = line) ---------------------------------------------------
+template <int DIR>
+__device__ inline void r16_decode1(R16Lds &sm, int line, int k)
 {
+    const unsigned *S = sm.S;
     unsigned cum = 0, cbg = 0;
     int G = -1;
-#pragma unroll 4
+#pragma unroll 8
     for (int g = 0; g < 32; g++) {
-        const unsigned s = sm.S[g * LINES + line];
+        const unsigned s = S[g * R16_LINES + line];
         const bool take = (G < 0) & ((int)(cum + s) >= k);
         G = take ? g : G;
         cbg = take ? cum : cbg;
@@ -68,9 +78,10 @@ __device__ inline void r16_decode1(R16Lds<LINES> &sm, int line, int k, CountFn c
     int B = -1;
     unsigned cb = 0;
     cum = cbg;
+    const int wd = r16_word<DIR>(line), sh = 16 * r16_half<DIR>(line);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const unsigned c = count_of(line, 8 * G + b);
+        const unsigned c = (sm.hist[(8 * G + b) * 32 + wd] >> sh) & 0xFFFFu;
         const bool take = (B < 0) & ((int)(cum + c) >= k);
         B = take ? 8 * G + b : B;
         cb = take ? cum : cb;
@@ -78,264 +89,184 @@ __device__ inline void r16_decode1(R16Lds<LINES> &sm, int line, int k, CountFn c
     }
     sm.lineB[line] = max(B, 0);
     sm.linecb[line] = (int)cb;
-    sm.cnt[line] = 0u;
-    sm.thx[line] = 0x3FFu;
-    sm.red[line] = 0u;
-    sm.rcnt[line] = 0u;
 }
 
-// ---- decode 2: sixteen lanes per line rank the line's list ----------------------------------------------------------------------
-// e = lane within the sixteen; `valid`: the line exists (its results are stored).  Writes t1 / item of the line (lane e == 0) and,
-// for a line whose reach holds other cells, the work item.  Returns the line's t1 (all sixteen lanes).
-template <int LINES>
-__device__ inline unsigned r16_decode2(R16Lds<LINES> &sm, int line, int e, bool valid, int k, int p, int dir, int which,
-                                       unsigned koff, bool adjacent_ok, const float *pair_band, const R16Work &w)
+// ---- decode 2: sixteen lanes per line (one DPP row), every thread of the block at once --------------------------------------------
+// Lane e of a line takes the line's e-th count by sixteens; a row scan finds the sixteen that holds the k-th smallest; lane e
+// then takes key 16 s + 1 + e of it and a second scan finds the key itself.  The lane that holds it decides (clean / work item)
+// and, for an item, the sixteen look through the hit slots of the threads that own the line's keys for the cells in reach.
+__device__ inline int r16_row_scan(int v)
 {
-    const unsigned nraw = sm.cnt[line];
-    const int n = (int)min(nraw, (unsigned)R16_CAP);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR1, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR2, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR4, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, DPP_ROW_SHR8, 0xf, 0xf, false);
+    return v;
+}
+
+template <int DIR>
+__device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int k, int p, int which, int item0, int tile_slot,
+                                   unsigned koff, bool adjacent_ok, const float *pair_band, const R16Work &w, uint16_t *t1_out,
+                                   int *item_out, int dbg)
+{
     const int B = sm.lineB[line], cb = sm.linecb[line];
-    const int need = k - cb;
-    const unsigned *lst = sm.lists + line * R16_LS;
-    unsigned ent[4], xe[4];
-    int lt[4], le[4];
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int m = e + 16 * a;
-        ent[a] = m < n ? lst[m] : R16_XNONE;
-        xe[a] = ent[a] & 0x1FFu;
-        lt[a] = le[a] = 0;
-    }
-    for (int m = 0; m < R16_CAP; m++) {
-        const bool act = m < n;
-        if (__ballot(act) == 0) break;
-        const unsigned xm = act ? (lst[m] & 0x1FFu) : R16_XNONE;
-        const bool inb = xm - 1u < 256u;
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            lt[a] += (inb & (xm < xe[a])) ? 1 : 0;
-            le[a] += (inb & (xm <= xe[a])) ? 1 : 0;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const bool win = (xe[a] - 1u < 256u) & (lt[a] < need) & (need <= le[a]);
-        if (win) { sm.thx[line] = xe[a]; sm.cle[line] = (unsigned)le[a]; }      // (equal keys: every winner writes the same pair)
-    }
+    const int need = k - cb;                               // >= 1: the rank of the k-th smallest inside bin B
+    const int c = (int)sm.sub[e * R16_LINES + line];
+    const int incl = r16_row_scan(c);
+    if ((incl - c < need) & (need <= incl)) sm.dec[line] = (unsigned)e | ((unsigned)(need - (incl - c)) << 8) | ((unsigned)(incl - c) << 20);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned thx = sm.thx[line];
-    const int cle = (int)sm.cle[line];
-    const int w0 = 256 * B - 1;                            // the key of x == 0
-    const unsigned th16 = (unsigned)(w0 + (int)thx);
-    bool ok = (thx <= 256u) & (nraw <= (unsigned)R16_CAP) & (B > 0) & (th16 < K16_MAX);
-    unsigned h_lo = 0, h_hi = 0;
-    k16_reach(ok ? th16 : (K16_FINE + 1u), koff, adjacent_ok, pair_band, h_lo, h_hi);
-    const int hlo_x = (int)h_lo - w0, hhi_x = (int)h_hi - w0;
-    ok = ok & (hlo_x >= 0) & (hhi_x <= (int)R16_XMAX) & (hlo_x <= (int)thx);
-    unsigned packed = 0;
-#pragma unroll
-    for (int a = 0; a < 4; a++) {
-        const int x = (int)xe[a];
-        if (x > (int)R16_XMAX) continue;
-        packed += ((x > (int)thx) & (x <= hhi_x)) ? 1u : 0u;                     // above the threshold key, inside the reach
-        packed += (x == 0) ? (1u << 8) : 0u;
-        packed += ((x >= 1) & (x < hlo_x)) ? (1u << 16) : 0u;
-        packed += ((x >= hlo_x) & (x <= hhi_x)) ? (1u << 24) : 0u;
-    }
-    if (packed) atomicAdd(&sm.red[line], packed);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned red = sm.red[line];
-    const int above = (int)(red & 0xFFu), n0 = (int)((red >> 8) & 0xFFu), nlow = (int)((red >> 16) & 0xFFu), nR = (int)(red >> 24);
-    const bool clean = ok & (cb + cle == k) & (above == 0);
+    const unsigned d1 = sm.dec[line];
+    bool ok = (d1 != 0x7FFFFFFFu) & (sm.ovf_n <= (unsigned)R16_OVF) & (B > 0);
+    const int sstar = (int)(d1 & 15u), r = (int)((d1 >> 8) & 0xFFFu), cums = (int)(d1 >> 20) & 0xFFF;
+    const int fq = line >> 2, fs = 8 * (line & 3);
+    const unsigned *fbase = sm.fine + (16 * sstar) * 16 + fq;        // x = 16 sstar + i
+    const int f = (int)((fbase[(1 + e) * 16] >> fs) & 0xFFu);       // this lane: x = 16 sstar + 1 + e
+    const int incl2 = r16_row_scan(f);
+    const bool mine = ok & (incl2 - f < r) & (r <= incl2);           // one lane of the sixteen
     unsigned t1 = 0;
-    int item = -1;
-    if (clean) t1 = th16 + 1u;
-    else if (ok) {
-        const int below = hlo_x == 0 ? cb - n0 : cb + nlow;
-        const int need2 = k - below;
-        ok = (need2 >= 1) & (need2 <= nR) & (nR <= R16_CAP);
-        if (ok) {
-            t1 = h_lo;
-            if (e == 0) {
-                int idx = valid ? atomicAdd(&w.counters[0], 1) : -1;
-                if (idx >= w.item_cap) idx = -2;
-                sm.item[line] = idx;
-                if (idx >= 0) {
-                    R16Item *it = w.items + idx;
-                    it->p = p; it->dir = dir; it->which = which; it->need = need2;
-                    it->n = nR; it->sel_lo = 0u; it->sel_hi = 0u; it->reserved = 0;
-                }
-            }
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            item = sm.item[line];
-            if (item >= 0) {
-#pragma unroll
-                for (int a = 0; a < 4; a++) {
-                    const int x = (int)xe[a];
-                    if ((x <= (int)R16_XMAX) & (x >= hlo_x) & (x <= hhi_x)) {
-                        const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
-                        w.items[item].pos[slot & (R16_CAP - 1)] = (uint16_t)(ent[a] >> 9);
+    int item = -1, hlo_x = 0, hhi_x = -1;
+    if (mine) {
+        const int thx = 16 * sstar + 1 + e;                // 1 .. 256
+        const int cle = cb + cums + incl2;                 // keys <= the threshold key
+        const int w0 = 256 * B - 1;                        // the key of x == 0
+        const unsigned th16 = (unsigned)(w0 + thx);
+        bool good = th16 < K16_MAX;
+        unsigned h_lo = 0, h_hi = 0;
+        k16_reach(good ? th16 : (K16_FINE + 1u), koff, adjacent_ok, pair_band, h_lo, h_hi);
+        hlo_x = (int)h_lo - w0;
+        hhi_x = (int)h_hi - w0;
+        good = good & (hlo_x >= thx - 1) & (hlo_x <= thx) & (hhi_x >= thx) & (hhi_x <= thx + 1);
+        const int c_m1 = (int)((fbase[e * 16] >> fs) & 0xFFu), c_p1 = (int)((fbase[(2 + e) * 16] >> fs) & 0xFFu);
+        const int above = hhi_x > thx ? c_p1 : 0, in_lo = hlo_x < thx ? c_m1 : 0;
+        if (good & (cle == k) & (above == 0)) t1 = th16 + 1u;
+        else if (good) {
+            // the cells in reach decide by exact value: those below the reach are selected, `need2` of the reach's cells too
+            const int nR = in_lo + f + above, below = cle - f - in_lo, need2 = k - below;
+            good = (need2 >= 1) & (need2 <= nR) & (nR <= R16_CAP);
+            if (good) {
+                t1 = h_lo;
+                if (valid && dbg != 8) {
+                    const int li = (int)atomicAdd(&sm.item_n, 1u);
+                    if (li < R16_TILE_ITEMS) item = item0 + li;
+                    else {
+                        item = w.static_items + atomicAdd(&w.counters[0], 1);
+                        if (item >= w.item_cap) { item = -1; good = false; }
+                    }
+                    if (item >= 0) {
+                        R16Item *it = w.items + item;
+                        it->p = p; it->dir = DIR; it->which = which; it->need = need2;
+                        it->n = nR; it->sel_lo = 0u; it->sel_hi = 0u; it->reserved = 0;
                     }
                 }
-            } else if (item == -2) ok = false;
-        }
-    }
-    if (!ok & valid & (e == 0)) {
-        w.pair_flag[p] = 1;
-        atomicAdd(&w.counters[1], 1);
-    }
-    if (!ok) { t1 = 0; item = -1; }
-    return (t1 & 0xFFFFu) | ((unsigned)(item >= 0) << 16);
-}
-
-// ---- columns --------------------------------------------------------------------------------------------------------------------
-// Block = 1024 threads = a tile of 64 columns x all rows (<= 1024) of one pair.  Thread (pi = t & 31, rs = t >> 5): column pair pi,
-// rows rs + 32 q -- a wave instruction reads two rows x 128 contiguous bytes.
-constexpr int R16C_THREADS = 1024;
-constexpr int R16C_COLS = 64;
-
-__global__ __launch_bounds__(R16C_THREADS, 8) void r16_cols_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
-                                                                   int win, double kv, int k_mode, R16Work w, int ldn, int col_blocks,
-                                                                   const float *__restrict__ band, const uint32_t *__restrict__ koff_of, int dbg)
-{
-    __shared__ __attribute__((aligned(16))) R16Lds<R16C_COLS> sm;
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int p = lb / col_blocks;
-    const int j0 = (lb % col_blocks) * R16C_COLS;
-    const acoss_pair_desc ds = descs[p];
-    const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    if (j0 >= N) return;
-    const int t = threadIdx.x;
-    const int k = knn_count(k_mode, kv, M);
-    uint16_t *t1_out = w.t1_col + (int64_t)p * ldn;
-    int *item_out = w.item_col + (int64_t)p * ldn;
-    if (k <= 0 || k >= M) {                                 // block-uniform: nothing / everything
-        if (t < R16C_COLS && j0 + t < N) { t1_out[j0 + t] = k <= 0 ? (uint16_t)0 : (uint16_t)0xFFFFu; item_out[j0 + t] = -1; }
-        return;
-    }
-    const int pi = t & 31, rs = t >> 5;
-    // ---- the tile's keys: 32 dwords per thread, all loads in flight before the first is used
-    const bool fast = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);
-    const int colp = min(j0 + 2 * pi, max(ds.crp_pitch - 2, 0));
-    const uint16_t *base = keys + ds.crp_off + colp + (int64_t)rs * ds.crp_pitch;
-    const int64_t rstep = 32 * (int64_t)ds.crp_pitch;
-    unsigned wv[32];
-    if (fast) {
-#pragma unroll
-        for (int q = 0; q < 32; q++)
-            wv[q] = rs + 32 * q < M ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
-    } else {
-#pragma unroll
-        for (int q = 0; q < 32; q++) {
-            const uint16_t *s = base + q * rstep;
-            wv[q] = rs + 32 * q < M ? ((unsigned)s[0] | ((unsigned)s[ds.crp_pitch > 1 ? 1 : 0] << 16)) : 0xFFFFFFFFu;
-        }
-    }
-    if (dbg == 1) {                                         // development: the loads alone
-        unsigned a = 0;
-#pragma unroll
-        for (int q = 0; q < 32; q++) a ^= wv[q];
-        if (a == 0x12345678u) t1_out[0] = 1;
-        return;
-    }
-    {
-        uint4 *hz = reinterpret_cast<uint4 *>(sm.hist);
-        hz[t] = make_uint4(0u, 0u, 0u, 0u);
-        hz[t + 1024] = make_uint4(0u, 0u, 0u, 0u);
-    }
-    lds_barrier();
-    // ---- pass 1: histogram over the high bytes.  Word [bin][pi]: low half = the pair's even column, high half = its odd column
-    const unsigned lanebase = r16_lds_off(sm.hist) + 4u * (unsigned)pi;
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-        const unsigned x = wv[q];
-        r16_lds_add(lanebase + ((x >> 1) & 0x7F80u), 1u);
-        r16_lds_add(lanebase + ((x >> 17) & 0x7F80u), 0x10000u);
-    }
-    lds_barrier();
-    if (dbg == 2) { if (sm.hist[t] == 0x12345678u) t1_out[0] = 1; return; }
-    // ---- decode 1
-    {
-        unsigned s = 0;
-#pragma unroll
-        for (int b = 0; b < 8; b++) s += sm.hist[(8 * rs + b) * 32 + pi];
-        sm.S[rs * R16C_COLS + 2 * pi] = s & 0xFFFFu;
-        sm.S[rs * R16C_COLS + 2 * pi + 1] = s >> 16;
-    }
-    lds_barrier();
-    if (t < R16C_COLS)
-        r16_decode1<R16C_COLS>(sm, t, k, [&](int line, int bin) { return (sm.hist[bin * 32 + (line >> 1)] >> (16 * (line & 1))) & 0xFFFFu; });
-    lds_barrier();
-    if (dbg == 3) { if (sm.lineB[t & 63] == 0x12345678) t1_out[0] = 1; return; }
-    // ---- pass 2: the keys inside each column's window, with their rows
-    {
-        const unsigned b0 = (unsigned)(256 * sm.lineB[2 * pi] - 1) & 0xFFFFu, b1 = (unsigned)(256 * sm.lineB[2 * pi + 1] - 1) & 0xFFFFu;
-        const u16x2 bsh = k16_from_u32(b0 | (b1 << 16));
-        unsigned *l0 = sm.lists + (2 * pi) * R16_LS, *l1 = l0 + R16_LS;
-#pragma unroll
-        for (int q = 0; q < 32; q++) {
-            const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
-            const unsigned xl = x & 0xFFFFu, xh = x >> 16;
-            const unsigned row = (unsigned)(rs + 32 * q);
-            if (xl <= R16_XMAX) {
-                const unsigned s = atomicAdd(&sm.cnt[2 * pi], 1u);
-                if (s < (unsigned)R16_CAP) l0[s] = xl | (row << 9);
-            }
-            if (xh <= R16_XMAX) {
-                const unsigned s = atomicAdd(&sm.cnt[2 * pi + 1], 1u);
-                if (s < (unsigned)R16_CAP) l1[s] = xh | (row << 9);
             }
         }
-    }
-    lds_barrier();
-    if (dbg == 4) { if (sm.cnt[t & 63] == 0x12345678u) t1_out[0] = 1; return; }
-    // ---- decode 2
-    {
-        const int line = t >> 4, e = t & 15;
-        const bool valid = j0 + line < N;
-        const unsigned koff = koff_of[p];
-        const float *pair_band = band + 2 * p;
-        const bool adjacent_ok = k16_reach_adjacent_ok(koff, pair_band);
-        const unsigned r = r16_decode2<R16C_COLS>(sm, line, e, valid, k, p, 1, j0 + line, koff, adjacent_ok, pair_band, w);
-        if (valid && e == 0) {
-            t1_out[j0 + line] = (uint16_t)(r & 0xFFFFu);
-            item_out[j0 + line] = (r >> 16) ? sm.item[line] : -1;
+        if (!good) { t1 = 0; item = -1; }
+        sm.t1[line] = t1;
+        sm.dec[line] = 0x80000000u | (unsigned)(item >= 0) | ((unsigned)(hlo_x & 0x1FF) << 1) | ((unsigned)(hhi_x & 0x1FF) << 10) | ((unsigned)good << 19);
+        sm.ditem[line] = item;
+        if (valid) {
+            if (!good) {
+                w.pair_flag[p] = 1;
+                atomicAdd(&w.counters[1], 1);
+            }
+            t1_out[which] = (uint16_t)t1;
+            item_out[which] = item;
         }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned d2 = sm.dec[line];
+    if (!(d2 & 0x80000000u)) {                              // no lane found the key (counts that do not add up: cannot happen)
+        if (e == 0) {
+            sm.t1[line] = 0u;
+            if (valid) { w.pair_flag[p] = 1; t1_out[which] = 0; item_out[which] = -1; }
+        }
+        return;
+    }
+    if (d2 & 1u) {
+        // the item's cells: lane e looks through the hits of the threads e (and e + 16) that hold keys of the line
+        const int lo = (int)((d2 >> 1) & 0x1FFu), hi = (int)((d2 >> 10) & 0x1FFu);
+        R16Item *it = w.items + sm.ditem[line];
+        const unsigned *hcnt = sm.S;
+        auto take = [&](const unsigned rec) {
+            const int x = (int)(rec & 0x1FFu);
+            if (((int)(rec >> 19) == line) & (x >= lo) & (x <= hi)) {
+                const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
+                it->pos[slot & (R16_CAP - 1)] = (uint16_t)((rec >> 9) & 0x3FFu);
+            }
+        };
+#pragma unroll
+        for (int o = e; o < (DIR ? 32 : 16); o += 16) {
+            const int owner = DIR ? (line >> 1) + 32 * o : 64 * (4 * (line >> 4) + (o & 3)) + (line & 15) + 16 * (o >> 2);
+            const int h = (int)hcnt[owner];
+            for (int q = 0; q < h; q++) take(sm.hist[q * R16_THREADS + owner]);
+        }
+        const int n_ovf = (int)min(sm.ovf_n, (unsigned)R16_OVF);
+        for (int o = e; o < n_ovf; o += 16) take(sm.S[1024 + o]);
     }
 }
 
-// ---- rows + the mutual mask's base bits -------------------------------------------------------------------------------------------
-// Block = 512 threads = a tile of 32 rows; wave v owns rows 4 v .. 4 v + 3, lane l the 8-column pieces l and l + 64 of each
-// (a wave instruction reads 1 KB of one row).  After the selection the same registers give the mask: bit = key < min(t1_row, t1_col),
-// one byte per lane and piece, 64 contiguous bytes per wave instruction.
-constexpr int R16R_THREADS = 512;
-constexpr int R16R_ROWS = 32;
-
-__global__ __launch_bounds__(R16R_THREADS, 6) void r16_rows_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
-                                                                   int win, double kv, int k_mode, R16Work w, int ldm, int ldn, int row_blocks,
-                                                                   const float *__restrict__ band, const uint32_t *__restrict__ koff_of,
-                                                                   int mutual, uint64_t *__restrict__ bits, int dbg)
+// ---- the selection kernel ------------------------------------------------------------------------------------------------------------
+// DIR 1, columns: a tile of 64 columns x all rows of one pair.  Thread (pi = t & 31, rs = t >> 5): column pair pi (the two halves
+//        of its dwords), rows rs + 32 q -- a wave instruction reads two rows x 128 contiguous bytes.
+// DIR 0, rows: a tile of 64 rows x all columns.  Wave v, lane l: row 16 (v >> 2) + (l & 15), 8-column pieces j + 16 q with
+//        j = (l >> 4) + 4 (v & 3) -- a wave instruction reads 64 contiguous bytes of each of sixteen rows, and the 32 lanes of an LDS
+//        lane group belong to sixteen different rows.  With both bounds known the row kernel writes the mutual mask's base bits
+//        key < min(t1_row, t1_col) from its registers.
+template <int DIR>
+__global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                    int win, double kv, int k_mode, R16Work w, int ldm, int ldn, int tiles,
+                                                                    const float *__restrict__ band, const uint32_t *__restrict__ koff_of,
+                                                                    int mutual, uint64_t *__restrict__ bits, int item0, int dbg)
 {
-    __shared__ __attribute__((aligned(16))) R16Lds<R16R_ROWS> sm;
+    __shared__ __attribute__((aligned(16))) R16Lds sm;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int p = lb / row_blocks;
-    const int i0 = (lb % row_blocks) * R16R_ROWS;
+    const int p = lb / tiles;
+    const int l0 = (lb % tiles) * R16_LINES;               // first line of the tile
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    if (i0 >= M) return;
+    const int n_lines = DIR ? N : M, n_pos = DIR ? M : N;
+    if (l0 >= n_lines) {
+        if (threadIdx.x == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = 0;
+        return;
+    }
     const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int k = knn_count(k_mode, kv, N);
-    const bool trivial = k <= 0 || k >= N;                  // block-uniform
+    const int k = knn_count(k_mode, kv, n_pos);
+    const bool trivial = k <= 0 || k >= n_pos;              // block-uniform: nothing / everything
+    uint16_t *t1_out = DIR ? w.t1_col + (int64_t)p * ldn : w.t1_row + (int64_t)p * ldm;
+    int *item_out = DIR ? w.item_col + (int64_t)p * ldn : w.item_row + (int64_t)p * ldm;
+    if (DIR == 1 && trivial) {
+        if (t < R16_LINES && l0 + t < n_lines) { t1_out[l0 + t] = k <= 0 ? (uint16_t)0 : (uint16_t)0xFFFFu; item_out[l0 + t] = -1; }
+        if (t == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = 0;
+        return;
+    }
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
-    // ---- keys: rows i0 + 4 wave + rr, pieces lane and lane + 64
-    const bool fast = ((ds.crp_pitch & 7) == 0) && ((ds.crp_off & 7) == 0);
-    unsigned wv[4][2][4];
+    // ---- the tile's keys: 32 dwords per thread, every load in flight before the first is used
+    unsigned wv[32];
+    const int pi = t & 31, rs = t >> 5;                     // columns
+    const int wave = t >> 6;
+    const int rr = 16 * (wave >> 2) + (lane & 15), jj = (lane >> 4) + 4 * (wave & 3);      // rows
+    if (DIR == 1) {
+        const bool fast = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);
+        const int colp = min(l0 + 2 * pi, max(ds.crp_pitch - 2, 0));
+        const uint16_t *base = keys + ds.crp_off + colp + (int64_t)rs * ds.crp_pitch;
+        const int64_t rstep = 32 * (int64_t)ds.crp_pitch;
+        if (fast) {
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int i = i0 + 4 * wave + rr;
+            for (int q = 0; q < 32; q++)
+                wv[q] = rs + 32 * q < M ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
+        } else {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-            const int c0 = 8 * (lane + 64 * h);
+            for (int q = 0; q < 32; q++) {
+                const uint16_t *s = base + q * rstep;
+                wv[q] = rs + 32 * q < M ? ((unsigned)s[0] | ((unsigned)s[ds.crp_pitch > 1 ? 1 : 0] << 16)) : 0xFFFFFFFFu;
+            }
+        }
+    } else {
+        const bool fast = ((ds.crp_pitch & 7) == 0) && ((ds.crp_off & 7) == 0);
+        const int i = l0 + rr;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const int c0 = 8 * (jj + 16 * q);
             u32x4v v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (i < M && c0 < N) {
                 const uint16_t *src = keys + ds.crp_off + (int64_t)i * ds.crp_pitch + c0;
@@ -356,145 +287,176 @@ __global__ __launch_bounds__(R16R_THREADS, 6) void r16_rows_kernel(const uint16_
                 }
             }
 #pragma unroll
-            for (int d = 0; d < 4; d++) wv[rr][h][d] = v[d];
+            for (int d = 0; d < 4; d++) wv[4 * q + d] = v[d];
+        }
+        if (t < 128) {
+            u32x4v tc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            if (mutual && 8 * t < N) tc = *reinterpret_cast<const u32x4v *>(w.t1_col + (int64_t)p * ldn + 8 * t);
+            sm.tcol[t] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
         }
     }
-    // the column bounds of this lane's two pieces (the same for all its rows)
-    u32x4v tc[2];
+    if (dbg == 1) {                                         // development: the loads alone
+        unsigned a = 0;
 #pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const int c0 = 8 * (lane + 64 * h);
-        tc[h] = (u32x4v){0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-        if (mutual && c0 < N) tc[h] = *reinterpret_cast<const u32x4v *>(w.t1_col + (int64_t)p * ldn + c0);
-    }
-    uint16_t *t1_out = w.t1_row + (int64_t)p * ldm;
-    int *item_out = w.item_row + (int64_t)p * ldm;
-    if (dbg == 1) {
-        unsigned a = tc[0][0] ^ tc[1][1];
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++)
-#pragma unroll
-            for (int h = 0; h < 2; h++)
-#pragma unroll
-                for (int d = 0; d < 4; d++) a ^= wv[rr][h][d];
+        for (int q = 0; q < 32; q++) a ^= wv[q];
         if (a == 0x12345678u) t1_out[0] = 1;
         return;
     }
     if (!trivial) {
         {
             uint4 *hz = reinterpret_cast<uint4 *>(sm.hist);
-#pragma unroll
-            for (int z = 0; z < 4; z++) hz[t + 512 * z] = make_uint4(0u, 0u, 0u, 0u);
+            hz[t] = make_uint4(0u, 0u, 0u, 0u);
+            hz[t + 1024] = make_uint4(0u, 0u, 0u, 0u);
+            uint4 *fz = reinterpret_cast<uint4 *>(sm.fine);
+            fz[t] = make_uint4(0u, 0u, 0u, 0u);
+            if (t < (int)(sizeof(sm.fine) / 16) - 1024) fz[t + 1024] = make_uint4(0u, 0u, 0u, 0u);
+            sm.sub[t] = 0u;
+            if (t == 0) { sm.ovf_n = 0u; sm.item_n = 0u; }
+            if (t < R16_LINES) { sm.dec[t] = 0x7FFFFFFFu; sm.rcnt[t] = 0u; }
         }
         lds_barrier();
-        // ---- pass 1: hist[row][bin]
+        // ---- pass 1: histogram over the high bytes
+        {
+            const unsigned lanebase = r16_lds_off(sm.hist) + 4u * (unsigned)(DIR ? pi : (rr & 31));
+            const unsigned vlo = DIR ? 1u : (rr < 32 ? 1u : 0x10000u), vhi = DIR ? 0x10000u : vlo;
 #pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const unsigned rowbase = r16_lds_off(sm.hist) + 1024u * (unsigned)(4 * wave + rr);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const unsigned x = wv[rr][h][d];
-                    r16_lds_add(rowbase + ((x >> 6) & 0x3FCu), 1u);
-                    r16_lds_add(rowbase + ((x >> 22) & 0x3FCu), 1u);
-                }
+            for (int q = 0; q < 32; q++) {
+                const unsigned x = wv[q];
+                r16_lds_add(lanebase + ((x >> 1) & 0x7F80u), vlo);
+                r16_lds_add(lanebase + ((x >> 17) & 0x7F80u), vhi);
             }
         }
         lds_barrier();
         if (dbg == 2) { if (sm.hist[t] == 0x12345678u) t1_out[0] = 1; return; }
-        // ---- decode 1: thread (g = t & 31, r = t >> 5): rows r and r + 16, bins 8 g .. 8 g + 7
+        // ---- decode 1
         {
-            const int g = t & 31, r = t >> 5;
+            unsigned s = 0;
 #pragma unroll
-            for (int z = 0; z < 2; z++) {
-                const uint4 a = reinterpret_cast<const uint4 *>(sm.hist + (r + 16 * z) * 256 + 8 * g)[0];
-                const uint4 b = reinterpret_cast<const uint4 *>(sm.hist + (r + 16 * z) * 256 + 8 * g)[1];
-                sm.S[g * R16R_ROWS + r + 16 * z] = (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w);
-            }
+            for (int b = 0; b < 8; b++) s += sm.hist[(8 * rs + b) * 32 + pi];
+            unsigned *S = sm.S;
+            S[rs * R16_LINES + (DIR ? 2 * pi : pi)] = s & 0xFFFFu;
+            S[rs * R16_LINES + (DIR ? 2 * pi + 1 : pi + 32)] = s >> 16;
         }
         lds_barrier();
-        if (t < R16R_ROWS) r16_decode1<R16R_ROWS>(sm, t, k, [&](int line, int bin) { return sm.hist[line * 256 + bin]; });
+        if (t < R16_LINES) r16_decode1<DIR>(sm, t, k);
         lds_barrier();
-        if (dbg == 3) { if (sm.lineB[t & 31] == 0x12345678) t1_out[0] = 1; return; }
-        // ---- pass 2
-#pragma unroll
-        for (int rr = 0; rr < 4; rr++) {
-            const int line = 4 * wave + rr;
-            const unsigned b0 = (unsigned)(256 * sm.lineB[line] - 1) & 0xFFFFu;
-            const u16x2 bsh = k16_from_u32(b0 | (b0 << 16));
-            unsigned *l0 = sm.lists + line * R16_LS;
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-#pragma unroll
-                for (int d = 0; d < 4; d++) {
-                    const unsigned x = k16_to_u32(k16_from_u32(wv[rr][h][d]) - bsh);
-                    const unsigned xl = x & 0xFFFFu, xh = x >> 16;
-                    const unsigned col = (unsigned)(8 * (lane + 64 * h) + 2 * d);
-                    if (xl <= R16_XMAX) {
-                        const unsigned s = atomicAdd(&sm.cnt[line], 1u);
-                        if (s < (unsigned)R16_CAP) l0[s] = xl | (col << 9);
-                    }
-                    if (xh <= R16_XMAX) {
-                        const unsigned s = atomicAdd(&sm.cnt[line], 1u);
-                        if (s < (unsigned)R16_CAP) l0[s] = xh | ((col + 1u) << 9);
-                    }
+        if (dbg == 3) { if (sm.lineB[t & 63] == 0x12345678) t1_out[0] = 1; return; }
+        // ---- pass 2: the keys inside each line's window: counted by sixteens and by key, listed with their positions
+        {
+            const int la = DIR ? 2 * pi : rr, lb2 = DIR ? 2 * pi + 1 : rr;
+            const unsigned b0 = (unsigned)(256 * sm.lineB[la] - 1) & 0xFFFFu, b1 = (unsigned)(256 * sm.lineB[lb2] - 1) & 0xFFFFu;
+            const u16x2 bsh = k16_from_u32(b0 | (b1 << 16));
+            // A hit is only KEPT inside the sweep -- x | position << 9 | line << 19 into the thread's own column of the slot table
+            // that takes the place of the histogram -- and counted afterwards, all lanes their q-th hit together: a block of the
+            // sweep runs for the whole wave when one lane hits (0.78 times per dword), the counting once per hit.
+            // (lines past the end of the matrix -- padding, or whatever lies behind a row -- take no part)
+            const unsigned lim_a = l0 + la < n_lines ? R16_XMAX + 1u : 0u, lim_b = l0 + lb2 < n_lines ? R16_XMAX + 1u : 0u;
+            unsigned hc = 0;
+            const unsigned slotbase = r16_lds_off(sm.hist) + 4u * (unsigned)t;
+            auto count = [&](const unsigned rec) {
+                const unsigned x = rec & 0x1FFu, line = rec >> 19;
+                if (x - 1u < 256u) atomicAdd(&sm.sub[((x - 1u) >> 4) * R16_LINES + line], 1u);
+                atomicAdd(&sm.fine[x * 16 + (line >> 2)], 1u << (8 * (line & 3)));
+            };
+            auto hit = [&](const unsigned rec) {
+                if (hc < (unsigned)R16_SLOTS) *(r16_lds_word *)(uintptr_t)(slotbase + hc * (4u * R16_THREADS)) = rec;
+                else {
+                    const unsigned oi = atomicAdd(&sm.ovf_n, 1u);
+                    if (oi < (unsigned)R16_OVF) sm.S[1024 + oi] = rec;
+                    count(rec);
                 }
+                hc++;
+            };
+            const unsigned rec_a = (unsigned)la << 19, rec_b = ((unsigned)lb2 << 19) | (DIR ? 0u : 1u << 9);
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
+                const unsigned xl = x & 0xFFFFu, xh = x >> 16;
+                const unsigned pos = DIR ? (unsigned)(rs + 32 * q) : (unsigned)(8 * (jj + 16 * (q >> 2)) + 2 * (q & 3));
+                if (xl < lim_a) hit((xl | (pos << 9)) + rec_a);
+                if (xh < lim_b) hit((xh | (pos << 9)) + rec_b);
+            }
+            const unsigned kept = min(hc, (unsigned)R16_SLOTS);
+            sm.S[t] = kept;
+            for (unsigned q = 0; q < (unsigned)R16_SLOTS; q++) {
+                if (__ballot(q < kept) == 0) break;
+                if (q < kept) count(*(const r16_lds_word *)(uintptr_t)(slotbase + q * (4u * R16_THREADS)));
             }
         }
         lds_barrier();
-        if (dbg == 4) { if (sm.cnt[t & 31] == 0x12345678u) t1_out[0] = 1; return; }
+        if (dbg == 4) { if (sm.S[t] == 0x12345678u) t1_out[0] = 1; return; }
         // ---- decode 2
         {
-            const int line = t >> 4, e = t & 15;
-            const bool valid = i0 + line < M;
             const unsigned koff = koff_of[p];
             const float *pair_band = band + 2 * p;
             const bool adjacent_ok = k16_reach_adjacent_ok(koff, pair_band);
-            const unsigned r = r16_decode2<R16R_ROWS>(sm, line, e, valid, k, p, 0, i0 + line, koff, adjacent_ok, pair_band, w);
-            if (e == 0) {
-                sm.t1[line] = r & 0xFFFFu;
-                if (valid) {
-                    t1_out[i0 + line] = (uint16_t)(r & 0xFFFFu);
-                    item_out[i0 + line] = (r >> 16) ? sm.item[line] : -1;
-                }
-            }
+            const int line = t >> 4;
+            r16_decode2<DIR>(sm, line, t & 15, l0 + line < n_lines, k, p, l0 + line, item0 + R16_TILE_ITEMS * lb, lb, koff, adjacent_ok,
+                             pair_band, w, t1_out, item_out, dbg);
+            lds_barrier();
+            if (t == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = (int)min(sm.item_n, (unsigned)R16_TILE_ITEMS);
         }
-        lds_barrier();
-    } else {
-        if (t < R16R_ROWS) {
+    } else {                                                // (rows only)
+        if (t < R16_LINES) {
             sm.t1[t] = k <= 0 ? 0u : 0xFFFFu;
-            if (i0 + t < M) { t1_out[i0 + t] = k <= 0 ? (uint16_t)0 : (uint16_t)0xFFFFu; item_out[i0 + t] = -1; }
+            if (l0 + t < n_lines) { t1_out[l0 + t] = k <= 0 ? (uint16_t)0 : (uint16_t)0xFFFFu; item_out[l0 + t] = -1; }
         }
+        if (t == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = 0;
         lds_barrier();
     }
+    if (DIR == 1) return;
     if (dbg == 5) return;
-    // ---- the mask's base bits
-    const u16x2 one = k16_opaque_ones();
-    unsigned char *ob = reinterpret_cast<unsigned char *>(bits) + ((int64_t)p * w.max_m + i0) * 128;
+    // ---- the mask's base bits: one byte per piece into LDS, then the tile's 64 x 128 bytes leave as one contiguous run
+    {
+        const u16x2 one = k16_opaque_ones();
+        const u16x2 tr = k16_splat(sm.t1[rr]);
+        unsigned char *mb = reinterpret_cast<unsigned char *>(sm.hist);
 #pragma unroll
-    for (int rr = 0; rr < 4; rr++) {
-        const int line = 4 * wave + rr;
-        if (i0 + line >= M) break;                          // wave-uniform
-        const u16x2 tr = k16_splat(sm.t1[line]);
-#pragma unroll
-        for (int h = 0; h < 2; h++) {
+        for (int q = 0; q < 8; q++) {
+            const int piece = jj + 16 * q;
+            const uint4 tc = sm.tcol[piece];
+            const unsigned tcv[4] = {tc.x, tc.y, tc.z, tc.w};
             unsigned acc = 0;
 #pragma unroll
             for (int d = 0; d < 4; d++) {
-                const u16x2 m1 = __builtin_elementwise_min(k16_from_u32(tc[h][d]), tr);
-                const u16x2 f = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m1, k16_from_u32(wv[rr][h][d])), one);
+                const u16x2 m1 = __builtin_elementwise_min(k16_from_u32(tcv[d]), tr);
+                const u16x2 f = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m1, k16_from_u32(wv[4 * q + d])), one);
                 acc |= k16_to_u32(f) << (2 * d);
             }
-            ob[line * 128 + lane + 64 * h] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);
+            mb[rr * 144 + piece] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);        // (144: the sixteen rows of a wave instruction meet two to a bank)
         }
+        lds_barrier();
+        if (t < 512 && l0 + (t >> 3) < M)
+            reinterpret_cast<uint4 *>(bits)[((int64_t)p * w.max_m + l0) * 8 + t] = reinterpret_cast<const uint4 *>(mb)[(t >> 3) * 9 + (t & 7)];
     }
 }
 
 // ---- exact values for the work items -------------------------------------------------------------------------------------------------
-// One wave per item: the item's cells (<= 64) get their exact windowed sums -- the arithmetic of fix_row_band_range
-// (planar_select.h): FMA chain over the bins of the rolled x frame, exact_term(), the nine terms added in window order in
-// float64 -- and the `need` smallest by (value, position) are selected.
+// Items live at R16_TILE_ITEMS * tile + slot (slot < tile_used[tile]) and behind w.static_items (counters[0] of them).  A wave
+// takes 64 consecutive indices, finds the ones that hold an item of an unflagged pair and works through them.
+// r16_item_list_kernel: the indices of the items of unflagged pairs, compacted (order irrelevant): counters[3] of them in item_list.
+__global__ __launch_bounds__(256) void r16_item_list_kernel(R16Work w)
+{
+    const int total = min(w.static_items + w.counters[0], w.item_cap);
+    const int lane = threadIdx.x & 63;
+    for (int s0 = 256 * blockIdx.x + (threadIdx.x & ~63); s0 < total; s0 += 256 * gridDim.x) {
+        const int s = s0 + lane;
+        bool valid = s < total;
+        if (valid && s < w.static_items) valid = (s & (R16_TILE_ITEMS - 1)) < w.tile_used[s / R16_TILE_ITEMS];
+        if (valid) valid = w.pair_flag[w.items[s].p] == 0;
+        const uint64_t m = __ballot(valid);
+        if (m == 0) continue;
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&w.counters[3], __popcll(m));
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int at = base + __popcll(m & ((1ull << lane) - 1ull));
+        if (valid && at < w.item_cap) w.item_list[at] = s;
+    }
+}
+
+// One item at a time, the wave together: the item's cells (<= 64) get their exact windowed sums -- the arithmetic of
+// fix_row_band_range (planar_select.h): FMA chain over the bins of the rolled x frame, exact_term(), the nine terms added in
+// window order in float64 -- and the `need` smallest by (value, position) are selected.
 template <typename FT>
 __global__ __launch_bounds__(64) void r16_exact_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
                                                        const acoss_pair_desc *__restrict__ descs, int win, R16Work w)
@@ -503,34 +465,41 @@ __global__ __launch_bounds__(64) void r16_exact_kernel(const FT *__restrict__ fe
     __shared__ unsigned long long key[R16_CAP];
     __shared__ int posv[R16_CAP];
     const int lane = threadIdx.x;
-    const int count = min(w.counters[0], w.item_cap);
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        R16Item *item = w.items + it;
+    const int count = min(w.counters[3], w.item_cap);
+    for (int li = blockIdx.x; li < count; li += gridDim.x) {
+        R16Item *item = w.items + w.item_list[li];
         const int p = item->p;
-        if (w.pair_flag[p]) continue;
         const int n = min(item->n, R16_CAP), need = item->need, dir = item->dir, which = item->which;
         const acoss_pair_desc ds = descs[p];
         if (lane < n) posv[lane] = (int)item->pos[lane];
         __syncthreads();
-        for (int c0 = 0; c0 < n; c0 += 7) {
-            const int g = lane / 9, kk = lane - 9 * g, el = c0 + g;
+        for (int e0 = 0; e0 < n; e0 += 7) {
+            const int g = lane / 9, kk = lane - 9 * g, el = e0 + g;
             if (lane < 63 && el < n) {
                 const int pos = posv[el];
                 const int i = dir == 0 ? which : pos, j = dir == 0 ? pos : which;
                 const FT *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
-                FT acc = 0;
-                for (int b = 0; b < d; b++) {
+                // (all of a frame pair's loads in flight at once, as in fix_row_band_range; d <= FIX_MAXD)
+                FT xv[FIX_MAXD], yv[FIX_MAXD];
+#pragma unroll
+                for (int b = 0; b < FIX_MAXD; b++) {
                     int src = b - ds.shift;
                     if (src < 0) src += d;
-                    acc = fma(x[src], y[b], acc);
+                    xv[b] = b < d ? x[src] : (FT)0;
+                    yv[b] = b < d ? y[b] : (FT)0;
                 }
-                cval[g * 9 + kk] = exact_term(acc, norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk]);
+                const FT nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
+                FT acc = 0;
+#pragma unroll
+                for (int b = 0; b < FIX_MAXD; b++)
+                    if (b < d) acc = fma(xv[b], yv[b], acc);
+                cval[g * 9 + kk] = exact_term(acc, nn);
             }
             __syncthreads();
-            if (lane < 7 && c0 + lane < n) {
+            if (lane < 7 && e0 + lane < n) {
                 double s_ = 0.0;
                 for (int q = 0; q < win; q++) s_ += cval[lane * 9 + q];
-                key[c0 + lane] = f64_key(s_);
+                key[e0 + lane] = f64_key(s_);
             }
             __syncthreads();
         }
@@ -549,35 +518,34 @@ __global__ __launch_bounds__(64) void r16_exact_kernel(const FT *__restrict__ fe
     }
 }
 
-// ---- the cells the items select, where the other side selects them too ---------------------------------------------------------------
+// ---- the cells the items select, where the other side selects them too (lane = item) ---------------------------------------------------
 __global__ __launch_bounds__(64) void r16_apply_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                        R16Work w, int ldm, int ldn, int mutual, uint64_t *__restrict__ bits)
 {
-    const int lane = threadIdx.x;
-    const int count = min(w.counters[0], w.item_cap);
-    for (int it = blockIdx.x; it < count; it += gridDim.x) {
-        const R16Item *item = w.items + it;
-        const int p = item->p;
-        if (w.pair_flag[p]) continue;
+    const int count = min(w.counters[3], w.item_cap);
+    for (int li = blockIdx.x * 64 + threadIdx.x; li < count; li += 64 * gridDim.x) {
+        const R16Item *item = w.items + w.item_list[li];
+        const int p = item->p, dir = item->dir, which = item->which;
         const uint64_t sel = ((uint64_t)item->sel_hi << 32) | item->sel_lo;
-        if (!((sel >> lane) & 1)) continue;
-        const int pos = (int)item->pos[lane];
-        const int i = item->dir == 0 ? item->which : pos, j = item->dir == 0 ? pos : item->which;
-        bool other = true;
-        if (mutual) {
-            const acoss_pair_desc ds = descs[p];
-            const unsigned key = keys[ds.crp_off + (int64_t)i * ds.crp_pitch + j];
-            const int oi = item->dir == 0 ? w.item_col[(int64_t)p * ldn + j] : w.item_row[(int64_t)p * ldm + i];
-            const unsigned t1 = item->dir == 0 ? w.t1_col[(int64_t)p * ldn + j] : w.t1_row[(int64_t)p * ldm + i];
-            other = key < t1;
-            if (!other && oi >= 0) {
-                const R16Item *o = w.items + oi;
-                const uint64_t osel = ((uint64_t)o->sel_hi << 32) | o->sel_lo;
-                const int want = item->dir == 0 ? i : j;
-                for (int m = 0; m < min(o->n, R16_CAP); m++) other |= ((osel >> m) & 1) && (int)o->pos[m] == want;
+        const acoss_pair_desc ds = descs[p];
+        for (uint64_t rest = sel; rest != 0; rest &= rest - 1) {
+            const int pos = (int)item->pos[__ffsll((unsigned long long)rest) - 1];
+            const int i = dir == 0 ? which : pos, j = dir == 0 ? pos : which;
+            bool other = true;
+            if (mutual) {
+                const unsigned key = keys[ds.crp_off + (int64_t)i * ds.crp_pitch + j];
+                const int oi = dir == 0 ? w.item_col[(int64_t)p * ldn + j] : w.item_row[(int64_t)p * ldm + i];
+                const unsigned t1 = dir == 0 ? w.t1_col[(int64_t)p * ldn + j] : w.t1_row[(int64_t)p * ldm + i];
+                other = key < t1;
+                if (!other && oi >= 0) {
+                    const R16Item *o = w.items + oi;
+                    const uint64_t osel = ((uint64_t)o->sel_hi << 32) | o->sel_lo;
+                    const int want = dir == 0 ? i : j;
+                    for (int m = 0; m < min(o->n, R16_CAP); m++) other |= ((osel >> m) & 1) && (int)o->pos[m] == want;
+                }
             }
+            if (other) atomicOr(reinterpret_cast<unsigned long long *>(bits) + ((int64_t)p * w.max_m + i) * 16 + (j >> 6), 1ull << (j & 63));
         }
-        if (other) atomicOr(reinterpret_cast<unsigned long long *>(bits) + ((int64_t)p * w.max_m + i) * 16 + (j >> 6), 1ull << (j & 63));
     }
 }
 
@@ -601,14 +569,14 @@ using namespace acoss;
 extern "C" size_t acoss_radix16_work_bytes(int K, int max_nx, int max_ny, int win)
 {
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    return r16_work_bytes(K, (max_m + 7) & ~7, (max_n + 7) & ~7);
+    return r16_work_bytes(K, max_m, max_n);
 }
 
 extern "C" int acoss_radix16_layout(void *work, int K, int max_nx, int max_ny, int win, void **ptrs, int *dims)
 {
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
-    const R16Work w = r16_work_layout(work, K, ldm, ldn);
+    const R16Work w = r16_work_layout(work, K, max_m, max_n);
     ptrs[0] = w.t1_row; ptrs[1] = w.t1_col; ptrs[2] = w.item_row; ptrs[3] = w.item_col; ptrs[4] = w.counters; ptrs[5] = w.items;
     ptrs[6] = w.pair_flag; ptrs[7] = w.pair_list;
     dims[0] = ldm; dims[1] = ldn; dims[2] = w.item_cap; dims[3] = (int)sizeof(R16Item);
@@ -623,31 +591,32 @@ static int radix16_run(int what, const uint16_t *keys16, const float *band, cons
 {
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
-    R16Work w = r16_work_layout(work, K, ldm, ldn);
-    w.max_m = max_m;
-    w.max_n = max_n;
+    R16Work w = r16_work_layout(work, K, max_m, max_n);
     double kv;
     int mode;
     if (kappa == 0.0) { kv = 0.0; mode = 2; } else if (kappa < 1.0) { kv = kappa; mode = 0; } else { kv = kappa; mode = 1; }
-    const int cb = ceil_div(max_n, R16C_COLS), rb = ceil_div(max_m, R16R_ROWS);
+    const int cb = ceil_div(max_n, R16_LINES), rb = ceil_div(max_m, R16_LINES);
     if ((int64_t)K * cb > 0x7fffffffLL || (int64_t)K * rb > 0x7fffffffLL) { set_error("radix16: batch too large"); return ACOSS_ENOTSUP; }
     if (what & 1) {
         ACOSS_HIP(hipMemsetAsync(w.counters, 0, 256, st));
         ACOSS_HIP(hipMemsetAsync(w.pair_flag, 0, (size_t)K, st));
         if (mutual) {
-            hipLaunchKernelGGL(r16_cols_kernel, dim3((unsigned)((int64_t)K * cb)), dim3(R16C_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldn, cb, band, koff, what >> 8);
-            const int rc = launch_check("r16_cols_kernel");
+            hipLaunchKernelGGL(r16_select_kernel<1>, dim3((unsigned)((int64_t)K * cb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, cb, band, koff, mutual, bits, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
+            const int rc = launch_check("r16_select_kernel<columns>");
             if (rc) return rc;
         }
     }
     if (what & 2) {
-        hipLaunchKernelGGL(r16_rows_kernel, dim3((unsigned)((int64_t)K * rb)), dim3(R16R_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, rb, band, koff, mutual, bits, what >> 8);
-        const int rc = launch_check("r16_rows_kernel");
+        hipLaunchKernelGGL(r16_select_kernel<0>, dim3((unsigned)((int64_t)K * rb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, rb, band, koff, mutual, bits, 0, (what >> 12) & 15);
+        const int rc = launch_check("r16_select_kernel<rows>");
         if (rc) return rc;
     }
     if (what & 4) {
+        ACOSS_HIP(hipMemsetAsync(w.counters + 3, 0, sizeof(int), st));
+        hipLaunchKernelGGL(r16_item_list_kernel, dim3(1024), dim3(256), 0, st, w);
         hipLaunchKernelGGL(r16_exact_kernel<FT>, dim3(8192), dim3(64), 0, st, feats, norms, d, descs, win, w);
-        hipLaunchKernelGGL(r16_apply_kernel, dim3(8192), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits);
+        if (what & 64) return launch_check("r16_exact_kernel");
+        hipLaunchKernelGGL(r16_apply_kernel, dim3(4096), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits);
         hipLaunchKernelGGL(r16_flag_list_kernel, dim3(1), dim3(256), 0, st, w, K);
         const int rc = launch_check("r16_exact_kernel / r16_apply_kernel");
         if (rc) return rc;

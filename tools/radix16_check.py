@@ -71,8 +71,10 @@ def old(mutual):
 stage(7)
 torch.cuda.synchronize()
 cn = counters.cpu().numpy()
-print("pairs %d  items %d (%.2f %% of rows + columns)  flagged lines %d  flagged pairs %d" % (
-    K, cn[0], 100.0 * cn[0] / max(1, sum(int(d["nx"]) + int(d["ny"]) - 16 for d in batch.descs)), cn[1], cn[2]))
+print("counters", cn[:4])
+nitems = int(((item_row.view(K, ldm) >= 0).sum() + (item_col.view(K, ldn) >= 0).sum()).item()) if cn[2] == 0 else -1
+print("pairs %d  items %d (%.2f %% of rows + columns; %d beyond the tiles' slots)  flagged lines %d  flagged pairs %d" % (
+    K, nitems, 100.0 * nitems / max(1, sum(int(d["nx"]) + int(d["ny"]) - 16 for d in batch.descs)), cn[0], cn[1], cn[2]))
 fl = flags.cpu().numpy().astype(bool)
 diff = (nbits.view(K, -1) != ref_bits.view(K, -1)).any(1).cpu().numpy()
 bad_pairs = [int(p) for p in np.nonzero(diff & ~fl)[0]]
@@ -110,9 +112,11 @@ def timed(fn, reps=6):
     return float(np.median(out[1:]))
 
 
+tc, tcr, tall = timed(lambda: stage(1)), timed(lambda: stage(3)), timed(lambda: stage(7))
+stage(3); torch.cuda.synchronize()
+print("direct: list + exact %.3f, list + exact + apply + flags %.3f;  by difference: list + exact %.3f" % (
+    timed(lambda: stage(4 | 64)), timed(lambda: stage(4)), timed(lambda: stage(7 | 64)) - tcr))
 print("ms per %d pairs:  radix cols %.3f  rows %.3f  exact+apply %.3f  all %.3f   | old rows %.3f cols %.3f mask_bits %.3f" % (
-    K, timed(lambda: stage(1)), timed(lambda: stage(2)), timed(lambda: stage(4)), timed(lambda: stage(7)),
-    timed(lambda: old(2)), timed(lambda: old(3)), timed(lambda: old(1))))
-
-for dbg in (1, 2, 3, 4, 5):
-    print("phase cut %d: cols %.3f rows %.3f" % (dbg, timed(lambda: stage(1 | (dbg << 8))), timed(lambda: stage(2 | (dbg << 8)))))
+    K, tc, tcr - tc, tall - tcr, tall, timed(lambda: old(2)), timed(lambda: old(3)), timed(lambda: old(1))))
+for dbg in (1, 2, 3, 4, 8, 5):
+    print("phase cut %d: cols %.3f rows %.3f" % (dbg, timed(lambda: stage(1 | (dbg << 8))), timed(lambda: stage(3 | (dbg << 12))) - tc))
