@@ -716,15 +716,21 @@ __device__ inline uint64_t spread_bits32(unsigned a)
 // (wave_transpose64) turns it, lane r ends with the row word of row ri*64 + r.
 constexpr int COMBINE_MAXW = 32;
 
+// (list != nullptr: the pairs list[0 .. *list_n), `slots` of them at a time -- the pairs the radix selection hands back)
 __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                            int mutual, ThreshWork w, int tiles_m,
-                                                           uint64_t *__restrict__ out)
+                                                           uint64_t *__restrict__ out, const int *__restrict__ list,
+                                                           const int *__restrict__ list_n, int slots)
 {
     __shared__ uint64_t rowbuf[64 * (COMBINE_MAXW + 1)];
-    const int p = blockIdx.x / tiles_m, ri = blockIdx.x % tiles_m;
+    const int ri = blockIdx.x % tiles_m;
+    const int n_list = list != nullptr ? *list_n : 1;
+    for (int s = list != nullptr ? blockIdx.x / tiles_m : 0; s < n_list; s += slots) {
+    const int p = list != nullptr ? list[s] : blockIdx.x / tiles_m;
+    __syncthreads();
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
-    if (ri * 64 >= M) return;
+    if (ri * 64 >= M) continue;
     const int W = w.wpr, ld = W + 1;
     const int rows = min(64, M - ri * 64);
     const int64_t base = ((int64_t)p * w.max_m + ri * 64) * W;          // the block's rows are contiguous: rows * W words
@@ -752,6 +758,7 @@ __global__ __launch_bounds__(256) void combine_bits_kernel(const acoss_pair_desc
     }
     __syncthreads();
     for (int idx = threadIdx.x; idx < rows * W; idx += 256) out[base + idx] = rowbuf[(idx / W) * ld + idx % W];
+    }
 }
 
 
@@ -1011,8 +1018,18 @@ int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual
 {
     const int tm = ceil_div(w.max_m, 64);       // every word of every row is written
     if (w.wpr > COMBINE_MAXW || (int64_t)K * tm > 0x7fffffffLL) { set_error("combine_bits: batch too large"); return ACOSS_ENOTSUP; }
-    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)((int64_t)K * tm)), dim3(256), 0, st, descs, K, win, mutual, w, tm, bits);
+    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)((int64_t)K * tm)), dim3(256), 0, st, descs, K, win, mutual, w, tm, bits,
+                       (const int *)nullptr, (const int *)nullptr, 1);
     return launch_check("combine_bits_kernel");
+}
+
+int launch_combine_bits_list(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, const int *list,
+                             const int *list_n, int slots, hipStream_t st)
+{
+    const int tm = ceil_div(w.max_m, 64);
+    if (w.wpr > COMBINE_MAXW) { set_error("combine_bits: batch too large"); return ACOSS_ENOTSUP; }
+    hipLaunchKernelGGL(combine_bits_kernel, dim3((unsigned)(slots * tm)), dim3(256), 0, st, descs, K, win, mutual, w, tm, bits, list, list_n, slots);
+    return launch_check("combine_bits_kernel (list)");
 }
 
 }  // namespace acoss

@@ -7,9 +7,10 @@
 // read with two 16-byte loads per lane (2 KB per wave, contiguous), the lane's 16 mask bits are exactly one uint16 of the
 // row's bit vector (no ballots, no lane transposition: 128 contiguous bytes per row leave the wave), and the per-key work
 // runs on packed 16-bit instructions.
-#include "keys16.h"
+#include "radix16.h"
 
 #include <stdlib.h>
+#include <string.h>
 
 namespace acoss {
 
@@ -57,17 +58,16 @@ constexpr int K16_ROWS_PER_WAVE = 32;
 
 // ---- rows ------------------------------------------------------------------------------------------------------------------
 template <int D>
-__global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
-                                                                 int win, double kv, int k_mode, ThreshWork w, int rows_blocks, K16Ctx cx)
+__device__ __forceinline__ void select_rows_k16_body(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                     int win, double kv, int k_mode, const ThreshWork &w, int rows_blocks, const K16Ctx &cx,
+                                                     const int p, const int sub)
 {
     __shared__ __attribute__((aligned(16))) unsigned hist_all[4 * K16_HIST_WORDS];
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int p = lb / rows_blocks;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
     const int rpw = (M + 4 * rows_blocks - 1) / (4 * rows_blocks);
-    const int r0 = ((lb % rows_blocks) * 4 + wave) * rpw;
+    const int r0 = (sub * 4 + wave) * rpw;
     if (r0 >= M) return;
     const int r1 = min(r0 + rpw, M);
     const int lane = threadIdx.x & 63;
@@ -146,6 +146,29 @@ __global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(cons
     if (lane == 0 && r0 == 0 && warm.hi != 0u) reinterpret_cast<unsigned *>(w.col_thr + (int64_t)p * w.max_n)[0] = warm.hi;
 }
 
+
+template <int D>
+__global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int rows_blocks, K16Ctx cx)
+{
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    select_rows_k16_body<D>(keys, descs, win, kv, k_mode, w, rows_blocks, cx, lb / rows_blocks, lb % rows_blocks);
+}
+
+// The same for the pairs of a list (round 5: the pairs the radix selection hands back -- exact ties); the grid covers `slots` pairs at a
+// time.  list_n: a device int.
+template <int D>
+__global__ __launch_bounds__(256, K16_ROWS_WPS) void select_rows_k16_list_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int rows_blocks, K16Ctx cx,
+                                                                 const int *__restrict__ list, const int *__restrict__ list_n, int slots)
+{
+    const int n = *list_n;
+    for (int s = blockIdx.x / rows_blocks; s < n; s += slots) {
+        select_rows_k16_body<D>(keys, descs, win, kv, k_mode, w, rows_blocks, cx, list[s], blockIdx.x % rows_blocks);
+        __syncthreads();
+    }
+}
+
 // ---- columns ---------------------------------------------------------------------------------------------------------------
 // One 8-wave block stages 32 columns (64-byte row segments) through LDS in two halves of 512 rows; wave v then selects in
 // columns 4v .. 4v+3, each inside the window predicted by the one before.  A thread loads 8 bytes (four columns) of two
@@ -169,14 +192,13 @@ constexpr int K16_COLS = 4 * K16_COL_WAVES;
 constexpr int K16_LDC = 265;            // words per staged half column: 8 x 33 + 1
 
 template <int D>
-__global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
-                                                                 int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx)
+__device__ __forceinline__ void select_cols_k16_body(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                     int win, double kv, int k_mode, const ThreshWork &w, int col_blocks, const K16Ctx &cx,
+                                                     const int p, const int sub)
 {
     __shared__ __attribute__((aligned(16))) unsigned colbuf[K16_COLS * K16_LDC + 8];
     __shared__ __attribute__((aligned(16))) unsigned hist_all[K16_COL_WAVES * K16_HIST_WORDS];
-    const int lb = xcd_remap(blockIdx.x, gridDim.x);
-    const int p = lb / col_blocks;
-    const int j0 = (lb % col_blocks) * K16_COLS;
+    const int j0 = sub * K16_COLS;
     const acoss_pair_desc ds = descs[p];
     const int M = ds.nx - win + 1, N = ds.ny - win + 1;
     if (j0 >= N) return;
@@ -295,17 +317,36 @@ __global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(
     pr.flush(cx.stats, lane);
 }
 
+
+template <int D>
+__global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx)
+{
+    const int lb = xcd_remap(blockIdx.x, gridDim.x);
+    select_cols_k16_body<D>(keys, descs, win, kv, k_mode, w, col_blocks, cx, lb / col_blocks, lb % col_blocks);
+}
+
+template <int D>
+__global__ __launch_bounds__(64 * K16_COL_WAVES, 6) void select_cols_k16_list_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+                                                                 int win, double kv, int k_mode, ThreshWork w, int col_blocks, K16Ctx cx,
+                                                                 const int *__restrict__ list, const int *__restrict__ list_n, int slots)
+{
+    const int n = *list_n;
+    for (int s = blockIdx.x / col_blocks; s < n; s += slots) {
+        select_cols_k16_body<D>(keys, descs, win, kv, k_mode, w, col_blocks, cx, list[s], blockIdx.x % col_blocks);
+        __syncthreads();
+    }
+}
+
 // ---- refinement ------------------------------------------------------------------------------------------------------------
 // One wave per side-buffer slot: exact float64 values of every cell whose 16-bit key the winner's error band can reach
 // (fix_row_band; the general bit-serial selection when more than 64 cells are in reach), cells with smaller keys are selected.
 template <typename FT>
-__global__ __launch_bounds__(64) void select_fix_side16_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
-                                                               const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
-                                                               ThreshWork w, const uint32_t *__restrict__ koff)
+__device__ __forceinline__ void select_fix_side16_body(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
+                                                       const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
+                                                       const ThreshWork &w, const uint32_t *__restrict__ koff, const int slot)
 {
     __shared__ FixSmem sm;
-    const int slot = blockIdx.x;
-    if (slot >= min(*w.side_counter, w.side_cap)) return;
     const int4 rec = w.side_slots[slot];
     const int p = rec.x, dir = rec.y, which = rec.z;
     const unsigned th = (unsigned)rec.w;
@@ -329,19 +370,34 @@ __global__ __launch_bounds__(64) void select_fix_side16_kernel(const FT *__restr
     }
 }
 
+
+template <typename FT>
+__global__ __launch_bounds__(64) void select_fix_side16_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
+                                                               const acoss_pair_desc *__restrict__ descs, int win, double kv, int k_mode,
+                                                               ThreshWork w, const uint32_t *__restrict__ koff)
+{
+    // (one slot per block when the grid is the slot capacity; a small grid walks the slots: the list form of the selection)
+    const int n = min(*w.side_counter, w.side_cap);
+    for (int slot = blockIdx.x; slot < n; slot += gridDim.x) {
+        select_fix_side16_body<FT>(feats, norms, d, descs, win, kv, k_mode, w, koff, slot);
+        __syncthreads();
+    }
+}
+
 // rows / columns that found no room in the side buffer (never, with its 2 % capacity, on real features): the same refinement
 // from the key plane itself
 template <int DIR, typename FT>
 __global__ __launch_bounds__(64) void select_fix_k16_kernel(const uint16_t *__restrict__ keys16, const FT *__restrict__ feats,
                                                             const FT *__restrict__ norms, int d, const acoss_pair_desc *__restrict__ descs,
                                                             int win, double kv, int k_mode, ThreshWork w, const uint32_t *__restrict__ koff,
-                                                            int groups, int64_t total)
+                                                            int groups, int64_t total, const int *__restrict__ list, const int *__restrict__ list_n)
 {
     __shared__ FixSmem sm;
     const int lane = threadIdx.x;
     if (w.side_counter != nullptr && *w.side_counter <= w.side_cap) return;
+    if (list != nullptr) total = (int64_t)(*list_n) * groups;
     for (int64_t blk = blockIdx.x; blk < total; blk += gridDim.x) {
-        const int p = (int)(blk / groups), g = (int)(blk % groups);
+        const int p = list != nullptr ? list[blk / groups] : (int)(blk / groups), g = (int)(blk % groups);
         const acoss_pair_desc ds = descs[p];
         const int M = ds.nx - win + 1, N = ds.ny - win + 1;
         const int count = DIR == 0 ? M : N;
@@ -449,6 +505,18 @@ __global__ __launch_bounds__(256) void k16_koff_pair_kernel(const float *__restr
 
 // defined in crp_kernels.hip
 int launch_combine_bits(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, hipStream_t st);
+int launch_combine_bits_list(const acoss_pair_desc *descs, int K, int win, int mutual, ThreshWork w, uint64_t *bits, const int *list,
+                             const int *list_n, int slots, hipStream_t st);
+
+// ACOSS_RADIX16 (default on; "0", "false", "no", "" switch it off): the radix selection of radix16_kernels.hip in front, the
+// wave-per-row kernels of this file only for the pairs it hands back.  Read at every call.
+static bool radix16_enabled()
+{
+    const char *e = getenv("ACOSS_RADIX16");
+    if (e == nullptr) return true;
+    return !(e[0] == 0 || strcmp(e, "0") == 0 || strcmp(e, "false") == 0 || strcmp(e, "no") == 0);
+}
+constexpr int K16_LIST_SLOTS = 8;          // pairs the list kernels cover at a time
 
 }  // namespace acoss
 
@@ -500,6 +568,28 @@ static int mask_bits_keys16_impl(const uint16_t *keys16, const float *band, cons
         else hipLaunchKernelGGL(select_cols_k16_kernel<13>, dim3((unsigned)((int64_t)K * cb)), dim3(64 * K16_COL_WAVES), 0, s, keys16, descs, win, kv, mode, w, cb, cx);
         return launch_check("select_cols_k16_kernel");
     };
+    if ((mutual == 0 || mutual == 1) && w.radix != nullptr && radix16_enabled()) {
+        // ---- round 5: radix selection (keys in registers, two passes), exact values for the few cells in reach, and the
+        // wave-per-row kernels below only for the pairs it cannot express (exact ties): their list stays on the device
+        rc = r16_run<FT>(7, keys16, band, koff, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, w.radix, st);
+        if (rc) return rc;
+        const R16Work rw = r16_work_layout(w.radix, K, max_m, max_n);
+        const int slots = K < K16_LIST_SLOTS ? K : K16_LIST_SLOTS;
+        const int *list = rw.pair_list, *list_n = rw.counters + 2;
+        if (d == 12) hipLaunchKernelGGL(select_rows_k16_list_kernel<12>, dim3((unsigned)(slots * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx, list, list_n, slots);
+        else hipLaunchKernelGGL(select_rows_k16_list_kernel<13>, dim3((unsigned)(slots * rb)), dim3(256), 0, st, keys16, descs, win, kv, mode, w, rb, cx, list, list_n, slots);
+        if (mutual) {
+            if (d == 12) hipLaunchKernelGGL(select_cols_k16_list_kernel<12>, dim3((unsigned)(slots * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx, list, list_n, slots);
+            else hipLaunchKernelGGL(select_cols_k16_list_kernel<13>, dim3((unsigned)(slots * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx, list, list_n, slots);
+        }
+        hipLaunchKernelGGL(select_fix_side16_kernel<FT>, dim3(256), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
+        const int gm2 = ceil_div(max_m, 64), gn2 = ceil_div(max_n, 64);
+        hipLaunchKernelGGL((select_fix_k16_kernel<0, FT>), dim3(256), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm2, (int64_t)K * gm2, list, list_n);
+        if (mutual) hipLaunchKernelGGL((select_fix_k16_kernel<1, FT>), dim3(256), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn2, (int64_t)K * gn2, list, list_n);
+        rc = launch_check("mask_bits_keys16_batch: list kernels");
+        if (rc) return rc;
+        return launch_combine_bits_list(descs, K, win, mutual, w, bits, list, list_n, slots, st);
+    }
     if (mutual != 3) {                          // (3 = measurement: the column selection kernel alone)
         rc = rows((unsigned)((int64_t)K * rb), st);
         if (rc) return rc;
@@ -514,8 +604,8 @@ static int mask_bits_keys16_impl(const uint16_t *keys16, const float *band, cons
     rc = launch_check("select_fix_side16_kernel");
     if (rc) return rc;
     const int gm = ceil_div(max_m, 64), gn = ceil_div(max_n, 64);
-    hipLaunchKernelGGL((select_fix_k16_kernel<0, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm, (int64_t)K * gm);
-    if (mutual) hipLaunchKernelGGL((select_fix_k16_kernel<1, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn, (int64_t)K * gn);
+    hipLaunchKernelGGL((select_fix_k16_kernel<0, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm, (int64_t)K * gm, (const int *)nullptr, (const int *)nullptr);
+    if (mutual) hipLaunchKernelGGL((select_fix_k16_kernel<1, FT>), dim3(2048), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn, (int64_t)K * gn, (const int *)nullptr, (const int *)nullptr);
     rc = launch_check("select_fix_k16_kernel (overflow)");
     if (rc) return rc;
     return launch_combine_bits(descs, K, win, mutual, w, bits, st);

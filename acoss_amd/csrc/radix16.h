@@ -41,35 +41,7 @@ struct R16Work {
     int max_m, max_n;
 };
 
-// Every tile of 64 lines owns R16_TILE_ITEMS item slots (no global atomic on the selection kernels' path; 2.5 of a tile's
-// lines need an item on the benchmark); a tile with more asks for single items behind them: room for 2 % of the lines.
-constexpr int R16_TILE_ITEMS = 8;
-constexpr int R16_TILE_LINES = 64;
-
-inline int r16_tiles(int K, int max_m, int max_n) { return K * ((max_m + R16_TILE_LINES - 1) / R16_TILE_LINES + (max_n + R16_TILE_LINES - 1) / R16_TILE_LINES); }
-
-inline int r16_item_cap(int K, int max_m, int max_n)
-{
-    const double lines = (double)K * (double)(max_m + max_n);
-    const double cap = (double)R16_TILE_ITEMS * (double)r16_tiles(K, max_m, max_n) + lines * 0.02 + 4096.0;
-    return cap > 4.0e7 ? 40000000 : (int)cap;
-}
-
-inline size_t r16_align(size_t b) { return (b + 255) & ~(size_t)255; }
-
-// ldm / ldn: row strides of the t1 / item arrays (the matrix sizes rounded up to 8)
-inline size_t r16_work_bytes(int K, int max_m, int max_n)
-{
-    const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
-    size_t b = 512;
-    b += r16_align((size_t)K * ldm * sizeof(uint16_t)) + r16_align((size_t)K * ldn * sizeof(uint16_t));
-    b += r16_align((size_t)K * ldm * sizeof(int)) + r16_align((size_t)K * ldn * sizeof(int));
-    b += r16_align((size_t)K * sizeof(int)) + r16_align((size_t)K);
-    b += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
-    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
-    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(R16Item));
-    return b + 256;
-}
+static_assert(sizeof(R16Item) == R16_ITEM_BYTES, "thresh_work.h sizes the workspace");
 
 inline R16Work r16_work_layout(void *work, int K, int max_m, int max_n)
 {
@@ -92,5 +64,12 @@ inline R16Work r16_work_layout(void *work, int K, int max_m, int max_n)
     w.max_n = max_n;
     return w;
 }
+
+// the selection on the keys of one batch (radix16_kernels.hip).  what: 1 columns, 2 rows + base bits, 4 exact values + the items'
+// cells + the list of flagged pairs (w.pair_list, w.counters[2]); `work`: r16_work_bytes() bytes (ThreshWork::radix)
+template <typename FT>
+int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t *koff, const FT *feats, const FT *norms, int d,
+            const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
+            void *work, hipStream_t st);
 
 }  // namespace acoss

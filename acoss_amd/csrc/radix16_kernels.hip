@@ -247,18 +247,21 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
     const int rr = 16 * (wave >> 2) + (lane & 15), jj = (lane >> 4) + 4 * (wave & 3);      // rows
     if (DIR == 1) {
         const bool fast = ((ds.crp_pitch & 1) == 0) && ((ds.crp_off & 1) == 0);
-        const int colp = min(l0 + 2 * pi, max(ds.crp_pitch - 2, 0));
-        const uint16_t *base = keys + ds.crp_off + colp + (int64_t)rs * ds.crp_pitch;
+        const int c0 = l0 + 2 * pi;
         const int64_t rstep = 32 * (int64_t)ds.crp_pitch;
         if (fast) {
+            // (column pairs past the pitch repeat the last pair: their lines do not exist)
+            const uint16_t *base = keys + ds.crp_off + min(c0, max(ds.crp_pitch - 2, 0)) + (int64_t)rs * ds.crp_pitch;
 #pragma unroll
             for (int q = 0; q < 32; q++)
                 wv[q] = rs + 32 * q < M ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
         } else {
+            const bool ha = c0 < ds.crp_pitch, hb = c0 + 1 < ds.crp_pitch;
+            const uint16_t *base = keys + ds.crp_off + (ha ? c0 : 0) + (int64_t)rs * ds.crp_pitch;
 #pragma unroll
             for (int q = 0; q < 32; q++) {
                 const uint16_t *s = base + q * rstep;
-                wv[q] = rs + 32 * q < M ? ((unsigned)s[0] | ((unsigned)s[ds.crp_pitch > 1 ? 1 : 0] << 16)) : 0xFFFFFFFFu;
+                wv[q] = rs + 32 * q < M ? ((ha ? (unsigned)s[0] : 0xFFFFu) | ((hb ? (unsigned)s[1] : 0xFFFFu) << 16)) : 0xFFFFFFFFu;
             }
         }
     } else {
@@ -302,6 +305,8 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         if (a == 0x12345678u) t1_out[0] = 1;
         return;
     }
+    // register dwords that can hold keys of the matrix (block-uniform; songs shorter than 1024 frames: the sweeps stop there)
+    const int q_end = DIR ? min(32, (M + 31) >> 5) : min(32, 4 * ((N + 127) >> 7));
     if (!trivial) {
         {
             uint4 *hz = reinterpret_cast<uint4 *>(sm.hist);
@@ -321,6 +326,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const unsigned vlo = DIR ? 1u : (rr < 32 ? 1u : 0x10000u), vhi = DIR ? 0x10000u : vlo;
 #pragma unroll
             for (int q = 0; q < 32; q++) {
+                if (q >= q_end) break;
                 const unsigned x = wv[q];
                 r16_lds_add(lanebase + ((x >> 1) & 0x7F80u), vlo);
                 r16_lds_add(lanebase + ((x >> 17) & 0x7F80u), vhi);
@@ -370,6 +376,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const unsigned rec_a = (unsigned)la << 19, rec_b = ((unsigned)lb2 << 19) | (DIR ? 0u : 1u << 9);
 #pragma unroll
             for (int q = 0; q < 32; q++) {
+                if (q >= q_end) break;
                 const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
                 const unsigned xl = x & 0xFFFFu, xh = x >> 16;
                 const unsigned pos = DIR ? (unsigned)(rs + 32 * q) : (unsigned)(8 * (jj + 16 * (q >> 2)) + 2 * (q & 3));
@@ -417,11 +424,13 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const uint4 tc = sm.tcol[piece];
             const unsigned tcv[4] = {tc.x, tc.y, tc.z, tc.w};
             unsigned acc = 0;
+            if (4 * q < q_end) {                            // (block-uniform; pieces behind the last column: zero bits)
 #pragma unroll
-            for (int d = 0; d < 4; d++) {
-                const u16x2 m1 = __builtin_elementwise_min(k16_from_u32(tcv[d]), tr);
-                const u16x2 f = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m1, k16_from_u32(wv[4 * q + d])), one);
-                acc |= k16_to_u32(f) << (2 * d);
+                for (int d = 0; d < 4; d++) {
+                    const u16x2 m1 = __builtin_elementwise_min(k16_from_u32(tcv[d]), tr);
+                    const u16x2 f = __builtin_elementwise_min(__builtin_elementwise_sub_sat(m1, k16_from_u32(wv[4 * q + d])), one);
+                    acc |= k16_to_u32(f) << (2 * d);
+                }
             }
             mb[rr * 144 + piece] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);        // (144: the sixteen rows of a wave instruction meet two to a bank)
         }
@@ -583,11 +592,15 @@ extern "C" int acoss_radix16_layout(void *work, int K, int max_nx, int max_ny, i
     return ACOSS_OK;
 }
 
-// what = 1: columns; 2: rows + base bits (needs the columns' t1 when mutual); 4: exact + apply.  Bits of `what` may be combined.
+// what = 1: columns; 2: rows + base bits (needs the columns' t1 when mutual); 4: item list + exact values (| 64: stop there)
+// + the items' cells + the list of flagged pairs.  Bits of `what` may be combined; bits 8-11 / 12-15: development phase cuts of
+// the column / row kernel.
+namespace acoss {
+
 template <typename FT>
-static int radix16_run(int what, const uint16_t *keys16, const float *band, const uint32_t *koff, const FT *feats, const FT *norms, int d,
-                       const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
-                       void *work, hipStream_t st)
+int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t *koff, const FT *feats, const FT *norms, int d,
+            const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits,
+            void *work, hipStream_t st)
 {
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;
@@ -604,7 +617,7 @@ static int radix16_run(int what, const uint16_t *keys16, const float *band, cons
             hipLaunchKernelGGL(r16_select_kernel<1>, dim3((unsigned)((int64_t)K * cb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, cb, band, koff, mutual, bits, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
             const int rc = launch_check("r16_select_kernel<columns>");
             if (rc) return rc;
-        }
+        } else ACOSS_HIP(hipMemsetAsync(w.tile_used + (size_t)K * rb, 0, (size_t)K * cb * sizeof(int), st));
     }
     if (what & 2) {
         hipLaunchKernelGGL(r16_select_kernel<0>, dim3((unsigned)((int64_t)K * rb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, rb, band, koff, mutual, bits, 0, (what >> 12) & 15);
@@ -624,6 +637,13 @@ static int radix16_run(int what, const uint16_t *keys16, const float *band, cons
     return ACOSS_OK;
 }
 
+template int r16_run<double>(int, const uint16_t *, const float *, const uint32_t *, const double *, const double *, int, const acoss_pair_desc *,
+                             int, int, int, int, double, int, uint64_t *, void *, hipStream_t);
+template int r16_run<float>(int, const uint16_t *, const float *, const uint32_t *, const float *, const float *, int, const acoss_pair_desc *,
+                            int, int, int, int, double, int, uint64_t *, void *, hipStream_t);
+
+}  // namespace acoss
+
 extern "C" int acoss_radix16_stage(int what, const uint16_t *keys16, const float *band, const uint32_t *koff, const double *feats,
                                    const double *norms, int d, const acoss_pair_desc *descs, int K, int win, int max_nx, int max_ny,
                                    double kappa, int mutual, uint64_t *bits, void *work, size_t work_bytes, void *stream)
@@ -636,5 +656,5 @@ extern "C" int acoss_radix16_stage(int what, const uint16_t *keys16, const float
     if (max_m > 1024 || max_n > 1024) { set_error("radix16_stage: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
     if (work_bytes < acoss_radix16_work_bytes(K, max_nx, max_ny, win)) { set_error("radix16_stage: workspace too small"); return ACOSS_EINVAL; }
     if (K == 0) return ACOSS_OK;
-    return radix16_run<double>(what, keys16, band, koff, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, (hipStream_t)stream);
+    return r16_run<double>(what, keys16, band, koff, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, (hipStream_t)stream);
 }

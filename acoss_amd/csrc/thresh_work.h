@@ -31,8 +31,40 @@ struct ThreshWork {
     int4 *side_slots;       // {pair, direction, index, high word the selection left}
     uint32_t *side_keys;    // [side_cap][1024]
     int side_cap;
+    void *radix;            // (bit-mask path up to 1024 x 1024) the radix selection's workspace: r16_work_layout(radix, K, max_m, max_n)
     __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };
+
+// ---- workspace of the radix selection (radix16.h lays it out; up to 1024 x 1024 only): behind the side buffer ---------------------
+// Every tile of 64 lines owns R16_TILE_ITEMS item slots (no global atomic on the selection kernels' path; 2.5 of a tile's lines
+// need an item on the benchmark); a tile with more asks for single items behind them: room for 2 % of the lines.
+constexpr int R16_TILE_ITEMS = 8;
+constexpr int R16_TILE_LINES = 64;
+constexpr size_t R16_ITEM_BYTES = 160;
+
+inline int r16_tiles(int K, int max_m, int max_n) { return K * ((max_m + R16_TILE_LINES - 1) / R16_TILE_LINES + (max_n + R16_TILE_LINES - 1) / R16_TILE_LINES); }
+
+inline int r16_item_cap(int K, int max_m, int max_n)
+{
+    const double lines = (double)K * (double)(max_m + max_n);
+    const double cap = (double)R16_TILE_ITEMS * (double)r16_tiles(K, max_m, max_n) + lines * 0.02 + 4096.0;
+    return cap > 4.0e7 ? 40000000 : (int)cap;
+}
+
+inline size_t r16_align(size_t b) { return (b + 255) & ~(size_t)255; }
+
+inline size_t r16_work_bytes(int K, int max_m, int max_n)
+{
+    const int ldm = (max_m + 7) & ~7, ldn = (max_n + 7) & ~7;      // row strides of the t1 / item arrays
+    size_t b = 512;
+    b += r16_align((size_t)K * ldm * sizeof(uint16_t)) + r16_align((size_t)K * ldn * sizeof(uint16_t));
+    b += r16_align((size_t)K * ldm * sizeof(int)) + r16_align((size_t)K * ldn * sizeof(int));
+    b += r16_align((size_t)K * sizeof(int)) + r16_align((size_t)K);
+    b += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
+    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
+    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * R16_ITEM_BYTES);
+    return b + 256;
+}
 
 // uint64 words per row of the bit planes and of the bit-packed mask: 16 up to 1024 x 1024, 32 up to 2048 x 2048
 inline int mask_bits_words(int max_m, int max_n) { return (max_m > 1024 || max_n > 1024) ? 32 : 16; }
@@ -50,7 +82,8 @@ inline size_t thresh_work_bytes(int K, int max_m, int max_n, bool with_bits)
     size_t b = (size_t)K * (size_t)(max_m + max_n) * (sizeof(uint64_t) + sizeof(int)) + 64;
     if (with_bits) {
         b += (size_t)K * (size_t)(max_m + max_n) * mask_bits_words(max_m, max_n) * sizeof(uint64_t) + 64;
-        if (mask_bits_words(max_m, max_n) == 16) b += 512 + (size_t)thresh_side_cap(K, max_m, max_n) * (sizeof(int4) + 1024 * sizeof(uint32_t));
+        if (mask_bits_words(max_m, max_n) == 16)
+            b += 512 + (size_t)thresh_side_cap(K, max_m, max_n) * (sizeof(int4) + 1024 * sizeof(uint32_t)) + 256 + r16_work_bytes(K, max_m, max_n);
     }
     return b;
 }
@@ -71,6 +104,7 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
     w.side_slots = nullptr;
     w.side_keys = nullptr;
     w.side_cap = 0;
+    w.radix = nullptr;
     w.wpr = mask_bits_words(max_m, max_n);
     if (with_bits) {
         uintptr_t a = (uintptr_t)(w.col_cut + (size_t)K * max_n);
@@ -84,6 +118,7 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
             w.side_cap = thresh_side_cap(K, max_m, max_n);
             w.side_slots = (int4 *)(a + 256);
             w.side_keys = (uint32_t *)(a + 256 + (size_t)w.side_cap * sizeof(int4));
+            w.radix = (void *)(((uintptr_t)(w.side_keys + (size_t)w.side_cap * 1024) + 255) & ~(uintptr_t)255);
         }
     }
     return w;
