@@ -324,12 +324,18 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         {
             const unsigned lanebase = r16_lds_off(sm.hist) + 4u * (unsigned)(DIR ? pi : (rr & 31));
             const unsigned vlo = DIR ? 1u : (rr < 32 ? 1u : 0x10000u), vhi = DIR ? 0x10000u : vlo;
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-                if (q >= q_end) break;
+            auto bin = [&](const int q) {
                 const unsigned x = wv[q];
                 r16_lds_add(lanebase + ((x >> 1) & 0x7F80u), vlo);
                 r16_lds_add(lanebase + ((x >> 17) & 0x7F80u), vhi);
+            };
+            if (q_end == 32) {                              // (block-uniform: the full-size form has no tests inside)
+#pragma unroll
+                for (int q = 0; q < 32; q++) bin(q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; q++)
+                    if (q < q_end) bin(q);
             }
         }
         lds_barrier();
@@ -374,14 +380,20 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                 hc++;
             };
             const unsigned rec_a = (unsigned)la << 19, rec_b = ((unsigned)lb2 << 19) | (DIR ? 0u : 1u << 9);
-#pragma unroll
-            for (int q = 0; q < 32; q++) {
-                if (q >= q_end) break;
+            auto test = [&](const int q) {
                 const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
                 const unsigned xl = x & 0xFFFFu, xh = x >> 16;
                 const unsigned pos = DIR ? (unsigned)(rs + 32 * q) : (unsigned)(8 * (jj + 16 * (q >> 2)) + 2 * (q & 3));
                 if (xl < lim_a) hit((xl | (pos << 9)) + rec_a);
                 if (xh < lim_b) hit((xh | (pos << 9)) + rec_b);
+            };
+            if (q_end == 32) {
+#pragma unroll
+                for (int q = 0; q < 32; q++) test(q);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 32; q++)
+                    if (q < q_end) test(q);
             }
             const unsigned kept = min(hc, (unsigned)R16_SLOTS);
             sm.S[t] = kept;
@@ -443,87 +455,169 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
 // ---- exact values for the work items -------------------------------------------------------------------------------------------------
 // Items live at R16_TILE_ITEMS * tile + slot (slot < tile_used[tile]) and behind w.static_items (counters[0] of them).  A wave
 // takes 64 consecutive indices, finds the ones that hold an item of an unflagged pair and works through them.
-// r16_item_list_kernel: the indices of the items of unflagged pairs, compacted (order irrelevant): counters[3] of them in item_list.
-__global__ __launch_bounds__(256) void r16_item_list_kernel(R16Work w)
+// ---- exact values for the work items -------------------------------------------------------------------------------------------------
+// The arithmetic of fix_row_band_range (planar_select.h): per cell nine terms -- FMA chain over the bins of the rolled x frame,
+// exact_term() -- added in window order in float64; within an item the `need` smallest cells by (value, position) are selected.
+// lanes (g, kk), g < 7: term kk of cell g; is_row: the cell is (which, pos), else (pos, which)
+template <typename FT>
+__device__ inline void r16_exact_term(const FT *__restrict__ feats, const FT *__restrict__ norms, int d, const acoss_pair_desc &ds,
+                                      bool is_row, int which, int pos, int kk, double *out)
 {
-    const int total = min(w.static_items + w.counters[0], w.item_cap);
-    const int lane = threadIdx.x & 63;
-    for (int s0 = 256 * blockIdx.x + (threadIdx.x & ~63); s0 < total; s0 += 256 * gridDim.x) {
-        const int s = s0 + lane;
-        bool valid = s < total;
-        if (valid && s < w.static_items) valid = (s & (R16_TILE_ITEMS - 1)) < w.tile_used[s / R16_TILE_ITEMS];
-        if (valid) valid = w.pair_flag[w.items[s].p] == 0;
-        const uint64_t m = __ballot(valid);
-        if (m == 0) continue;
-        int base = 0;
-        if (lane == 0) base = atomicAdd(&w.counters[3], __popcll(m));
-        base = __builtin_amdgcn_readfirstlane(base);
-        const int at = base + __popcll(m & ((1ull << lane) - 1ull));
-        if (valid && at < w.item_cap) w.item_list[at] = s;
+    const int i = is_row ? which : pos, j = is_row ? pos : which;
+    const FT *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
+    // (all of a frame pair's loads in flight at once; d <= FIX_MAXD)
+    FT xv[FIX_MAXD], yv[FIX_MAXD];
+#pragma unroll
+    for (int b = 0; b < FIX_MAXD; b++) {
+        int src = b - ds.shift;
+        if (src < 0) src += d;
+        xv[b] = b < d ? x[src] : (FT)0;
+        yv[b] = b < d ? y[b] : (FT)0;
+    }
+    const FT nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
+    FT acc = 0;
+#pragma unroll
+    for (int b = 0; b < FIX_MAXD; b++)
+        if (b < d) acc = fma(xv[b], yv[b], acc);
+    *out = exact_term(acc, nn);
+}
+
+struct R16ExactSmem {
+    double cval[64];
+    unsigned long long key[R16_CAP];
+    int posv[R16_CAP], citem[R16_CAP];
+    uint4 rec[R16_TILE_ITEMS * 10];              // a tile's item records
+};
+
+// one item, the wave together (items with more than a handful of cells, and the items behind the tiles' own slots)
+template <typename FT>
+__device__ inline void r16_exact_item(R16ExactSmem &sm, R16Item *item, const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
+                                      const acoss_pair_desc &ds, int win, int lane)
+{
+    const int n = min(item->n, R16_CAP), need = item->need, dir = item->dir, which = item->which;
+    if (lane < n) sm.posv[lane] = (int)item->pos[lane];
+    __syncthreads();
+    for (int e0 = 0; e0 < n; e0 += 7) {
+        const int g = lane / 9, kk = lane - 9 * g, el = e0 + g;
+        if (lane < 63 && el < n) r16_exact_term<FT>(feats, norms, d, ds, dir == 0, which, sm.posv[el], kk, &sm.cval[g * 9 + kk]);
+        __syncthreads();
+        if (lane < 7 && e0 + lane < n) {
+            double s_ = 0.0;
+            for (int q = 0; q < win; q++) s_ += sm.cval[lane * 9 + q];
+            sm.key[e0 + lane] = f64_key(s_);
+        }
+        __syncthreads();
+    }
+    int rank = 1;
+    unsigned long long mykey = 0;
+    int mypos = 0;
+    if (lane < n) { mykey = sm.key[lane]; mypos = sm.posv[lane]; }
+    for (int m = 0; m < n; m++) {
+        const unsigned long long km = sm.key[m];
+        const int pm = sm.posv[m];
+        rank += ((km < mykey) | ((km == mykey) & (pm < mypos))) ? 1 : 0;
+    }
+    const unsigned long long sel = __ballot(lane < n && rank <= need);
+    if (lane == 0) { item->sel_lo = (unsigned)sel; item->sel_hi = (unsigned)(sel >> 32); }
+    __syncthreads();
+}
+
+// A wave per TILE: the tile's eight item records arrive in one round trip (the pair follows from the tile's index), the cells of
+// all its items are evaluated together -- two dependent round trips to memory per tile instead of four per item.
+template <typename FT>
+__global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
+                                                             const acoss_pair_desc *__restrict__ descs, int win, R16Work w,
+                                                             int row_tiles, int rb, int cb)
+{
+    __shared__ R16ExactSmem sm;
+    const int lane = threadIdx.x;
+    const int n_tiles = w.static_items / R16_TILE_ITEMS;
+    for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+        const int used = min(w.tile_used[tile], R16_TILE_ITEMS);
+        if (used <= 0) continue;
+        const int p = tile < row_tiles ? tile / rb : (tile - row_tiles) / cb;
+        if (w.pair_flag[p]) continue;
+        R16Item *items = w.items + (int64_t)R16_TILE_ITEMS * tile;
+        const uint4 *src = reinterpret_cast<const uint4 *>(items);
+        sm.rec[lane] = src[lane];
+        if (lane < R16_TILE_ITEMS * 10 - 64) sm.rec[64 + lane] = src[64 + lane];
+        const acoss_pair_desc ds = descs[p];
+        __syncthreads();
+        // the tile's cells, item after item
+        int start = 0, mine = -1, n_mine = 0, total = 0;
+#pragma unroll
+        for (int l = 0; l < R16_TILE_ITEMS; l++) {
+            const int nl = l < used ? min((int)sm.rec[10 * l + 1].x, R16_CAP) : 0;
+            if (lane >= total && lane < total + nl) { mine = l; start = total; n_mine = nl; }
+            total += nl;
+        }
+        if (total > 64) {                                    // (rare: an item with many cells in reach) one item at a time
+            for (int l = 0; l < used; l++) r16_exact_item<FT>(sm, items + l, feats, norms, d, ds, win, lane);
+            continue;
+        }
+        if (mine >= 0) {
+            sm.citem[lane] = mine;
+            sm.posv[lane] = (int)reinterpret_cast<const uint16_t *>(&sm.rec[10 * mine + 2])[lane - start];
+        }
+        __syncthreads();
+        for (int e0 = 0; e0 < total; e0 += 7) {
+            const int g = lane / 9, kk = lane - 9 * g, el = e0 + g;
+            if (lane < 63 && el < total) {
+                const int l = sm.citem[el];
+                const uint4 hdr = sm.rec[10 * l];
+                r16_exact_term<FT>(feats, norms, d, ds, hdr.y == 0u, (int)hdr.z, sm.posv[el], kk, &sm.cval[g * 9 + kk]);
+            }
+            __syncthreads();
+            if (lane < 7 && e0 + lane < total) {
+                double s_ = 0.0;
+                for (int q = 0; q < win; q++) s_ += sm.cval[lane * 9 + q];
+                sm.key[e0 + lane] = f64_key(s_);
+            }
+            __syncthreads();
+        }
+        bool sel = false;
+        if (mine >= 0) {
+            const unsigned long long mykey = sm.key[lane];
+            const int mypos = sm.posv[lane], need = (int)sm.rec[10 * mine].w;
+            int rank = 1;
+            for (int m = start; m < start + n_mine; m++) {
+                const unsigned long long km = sm.key[m];
+                const int pm = sm.posv[m];
+                rank += ((km < mykey) | ((km == mykey) & (pm < mypos))) ? 1 : 0;
+            }
+            sel = rank <= need;
+        }
+        const unsigned long long all = __ballot(sel);
+        // lane l < used writes item l's selection: its cells are lanes [start_l, start_l + n_l)
+        {
+            int st = 0;
+            unsigned long long m_l = 0;
+#pragma unroll
+            for (int l = 0; l < R16_TILE_ITEMS; l++) {
+                const int nl = l < used ? min((int)sm.rec[10 * l + 1].x, R16_CAP) : 0;
+                if (l == lane) m_l = nl >= 64 ? all : ((all >> st) & ((1ull << nl) - 1ull));
+                st += nl;
+            }
+            if (lane < used) { items[lane].sel_lo = (unsigned)m_l; items[lane].sel_hi = (unsigned)(m_l >> 32); }
+        }
+        __syncthreads();
     }
 }
 
-// One item at a time, the wave together: the item's cells (<= 64) get their exact windowed sums -- the arithmetic of
-// fix_row_band_range (planar_select.h): FMA chain over the bins of the rolled x frame, exact_term(), the nine terms added in
-// window order in float64 -- and the `need` smallest by (value, position) are selected.
+// the items behind the tiles' own slots (tiles with more than R16_TILE_ITEMS unclean lines: a few hundred per batch)
 template <typename FT>
-__global__ __launch_bounds__(64) void r16_exact_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
-                                                       const acoss_pair_desc *__restrict__ descs, int win, R16Work w)
+__global__ __launch_bounds__(64) void r16_exact_extra_kernel(const FT *__restrict__ feats, const FT *__restrict__ norms, int d,
+                                                             const acoss_pair_desc *__restrict__ descs, int win, R16Work w)
 {
-    __shared__ double cval[64];
-    __shared__ unsigned long long key[R16_CAP];
-    __shared__ int posv[R16_CAP];
+    __shared__ R16ExactSmem sm;
     const int lane = threadIdx.x;
-    const int count = min(w.counters[3], w.item_cap);
-    for (int li = blockIdx.x; li < count; li += gridDim.x) {
-        R16Item *item = w.items + w.item_list[li];
+    const int total = min(w.static_items + w.counters[0], w.item_cap);
+    for (int it = w.static_items + blockIdx.x; it < total; it += gridDim.x) {
+        R16Item *item = w.items + it;
         const int p = item->p;
-        const int n = min(item->n, R16_CAP), need = item->need, dir = item->dir, which = item->which;
+        if (w.pair_flag[p]) continue;
         const acoss_pair_desc ds = descs[p];
-        if (lane < n) posv[lane] = (int)item->pos[lane];
-        __syncthreads();
-        for (int e0 = 0; e0 < n; e0 += 7) {
-            const int g = lane / 9, kk = lane - 9 * g, el = e0 + g;
-            if (lane < 63 && el < n) {
-                const int pos = posv[el];
-                const int i = dir == 0 ? which : pos, j = dir == 0 ? pos : which;
-                const FT *x = feats + (ds.x_row0 + i + kk) * d, *y = feats + (ds.y_row0 + j + kk) * d;
-                // (all of a frame pair's loads in flight at once, as in fix_row_band_range; d <= FIX_MAXD)
-                FT xv[FIX_MAXD], yv[FIX_MAXD];
-#pragma unroll
-                for (int b = 0; b < FIX_MAXD; b++) {
-                    int src = b - ds.shift;
-                    if (src < 0) src += d;
-                    xv[b] = b < d ? x[src] : (FT)0;
-                    yv[b] = b < d ? y[b] : (FT)0;
-                }
-                const FT nn = norms[ds.x_row0 + i + kk] + norms[ds.y_row0 + j + kk];
-                FT acc = 0;
-#pragma unroll
-                for (int b = 0; b < FIX_MAXD; b++)
-                    if (b < d) acc = fma(xv[b], yv[b], acc);
-                cval[g * 9 + kk] = exact_term(acc, nn);
-            }
-            __syncthreads();
-            if (lane < 7 && e0 + lane < n) {
-                double s_ = 0.0;
-                for (int q = 0; q < win; q++) s_ += cval[lane * 9 + q];
-                key[e0 + lane] = f64_key(s_);
-            }
-            __syncthreads();
-        }
-        int rank = 1;
-        unsigned long long mykey = 0;
-        int mypos = 0;
-        if (lane < n) { mykey = key[lane]; mypos = posv[lane]; }
-        for (int m = 0; m < n; m++) {
-            const unsigned long long km = key[m];
-            const int pm = posv[m];
-            rank += ((km < mykey) | ((km == mykey) & (pm < mypos))) ? 1 : 0;
-        }
-        const unsigned long long sel = __ballot(lane < n && rank <= need);
-        if (lane == 0) { item->sel_lo = (unsigned)sel; item->sel_hi = (unsigned)(sel >> 32); }
-        __syncthreads();
+        r16_exact_item<FT>(sm, item, feats, norms, d, ds, win, lane);
     }
 }
 
@@ -531,10 +625,12 @@ __global__ __launch_bounds__(64) void r16_exact_kernel(const FT *__restrict__ fe
 __global__ __launch_bounds__(64) void r16_apply_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                        R16Work w, int ldm, int ldn, int mutual, uint64_t *__restrict__ bits)
 {
-    const int count = min(w.counters[3], w.item_cap);
-    for (int li = blockIdx.x * 64 + threadIdx.x; li < count; li += 64 * gridDim.x) {
-        const R16Item *item = w.items + w.item_list[li];
+    const int total = min(w.static_items + w.counters[0], w.item_cap);
+    for (int s = blockIdx.x * 64 + threadIdx.x; s < total; s += 64 * gridDim.x) {
+        if (s < w.static_items && (s & (R16_TILE_ITEMS - 1)) >= w.tile_used[s / R16_TILE_ITEMS]) continue;
+        const R16Item *item = w.items + s;
         const int p = item->p, dir = item->dir, which = item->which;
+        if (w.pair_flag[p]) continue;
         const uint64_t sel = ((uint64_t)item->sel_hi << 32) | item->sel_lo;
         const acoss_pair_desc ds = descs[p];
         for (uint64_t rest = sel; rest != 0; rest &= rest - 1) {
@@ -625,10 +721,9 @@ int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t 
         if (rc) return rc;
     }
     if (what & 4) {
-        ACOSS_HIP(hipMemsetAsync(w.counters + 3, 0, sizeof(int), st));
-        hipLaunchKernelGGL(r16_item_list_kernel, dim3(1024), dim3(256), 0, st, w);
-        hipLaunchKernelGGL(r16_exact_kernel<FT>, dim3(8192), dim3(64), 0, st, feats, norms, d, descs, win, w);
-        if (what & 64) return launch_check("r16_exact_kernel");
+        hipLaunchKernelGGL(r16_exact_tiles_kernel<FT>, dim3(8192), dim3(64), 0, st, feats, norms, d, descs, win, w, K * rb, rb, cb);
+        hipLaunchKernelGGL(r16_exact_extra_kernel<FT>, dim3(256), dim3(64), 0, st, feats, norms, d, descs, win, w);
+        if (what & 64) return launch_check("r16_exact_tiles_kernel");
         hipLaunchKernelGGL(r16_apply_kernel, dim3(4096), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits);
         hipLaunchKernelGGL(r16_flag_list_kernel, dim3(1), dim3(256), 0, st, w, K);
         const int rc = launch_check("r16_exact_kernel / r16_apply_kernel");
