@@ -34,17 +34,31 @@ __device__ inline void r16_lds_add(unsigned byte_off, unsigned v)
     __hip_atomic_fetch_add((r16_lds_word *)(uintptr_t)byte_off, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// column loads: a 32-column tile reads half a cache line per row and the neighbouring tile (the next block) the other half --
+// plain loads leave the line in L2 for it, non-temporal ones do not
+#ifndef R16_COL_NT
+#define R16_COL_NT 0
+#endif
+#if R16_COL_NT
+#define R16_COL_LOAD(p) __builtin_nontemporal_load(p)
+#else
+#define R16_COL_LOAD(p) (*(p))
+#endif
 constexpr unsigned R16_XMAX = 257u;      // captured window: x = key - (256 B - 1) in [0, 257]
-constexpr int R16_THREADS = 1024;        // sixteen waves per block
+constexpr int R16_THREADS = 16 * R16_TILE_LINES;   // sixteen threads per line
+constexpr int R16_WORDS = R16_TILE_LINES / 2;      // histogram words per bin (two lines each)
+constexpr int R16_BINSHIFT = R16_WORDS == 32 ? 1 : 2;        // key >> (8 + BINSHIFT) << ... : byte offset of a bin = bin * 4 * WORDS
+constexpr unsigned R16_BINMASK = 0xFFu * 4u * R16_WORDS;
+static_assert(R16_TILE_LINES == 64 || R16_TILE_LINES == 32, "block geometry");
 constexpr int R16_LINES = R16_TILE_LINES; // columns (rows) per block
 
 // Line l of a tile has its pass-1 counts in half (DIR ? l & 1 : l >> 5) of word (DIR ? l >> 1 : l & 31) of every histogram bin:
 // a column kernel lane owns two neighbouring columns (one dword of a row), the rows of a row-kernel LDS lane group differ in
 // their low five bits -- either way the lanes of a group add into different banks.
 struct R16Lds {
-    unsigned hist[8192];                       // pass 1: [bin][32 words]; pass 2: every thread's hits [slot][thread]; row kernel, last: the mask bytes
+    unsigned hist[256 * R16_WORDS];            // pass 1: [bin][words]; pass 2: every thread's hits [slot][thread]; row kernel, last: the mask bytes
     unsigned S[32 * R16_LINES];                // decode 1: the counts summed over groups of eight bins, [group][line]; then hcnt[thread]
-    unsigned fine[(R16_XMAX + 1) * 16];        // [x][line >> 2]: byte (line & 3) = the line's keys with that x
+    unsigned fine[(R16_XMAX + 1) * (R16_LINES / 4)];      // [x][line >> 2]: byte (line & 3) = the line's keys with that x
     unsigned sub[16 * R16_LINES];              // [(x - 1) >> 4][line]: the line's keys inside bin B, by sixteens
     int lineB[R16_LINES], linecb[R16_LINES];
     unsigned t1[R16_LINES];
@@ -54,10 +68,10 @@ struct R16Lds {
     uint4 tcol[128];                           // row kernel: the pair's column bounds
 };
 constexpr int R16_SLOTS = 8;                   // hits a thread can hold (x | position << 9 | line << 19 each); further ones go to
-constexpr int R16_OVF = 1024;                  // the block's overflow list: the upper half of S
+constexpr int R16_OVF = 32 * R16_TILE_LINES - 16 * R16_TILE_LINES;      // the block's overflow list: the part of S behind hcnt[thread]
 
-template <int DIR> __device__ inline int r16_word(int line) { return DIR ? line >> 1 : line & 31; }
-template <int DIR> __device__ inline int r16_half(int line) { return DIR ? line & 1 : line >> 5; }
+template <int DIR> __device__ inline int r16_word(int line) { return DIR ? line >> 1 : line & (R16_WORDS - 1); }
+template <int DIR> __device__ inline int r16_half(int line) { return DIR ? line & 1 : line / R16_WORDS; }
 
 // ---- decode 1: the high byte of every line's k-th smallest key (lane = line) ---------------------------------------------------
 template <int DIR>
@@ -81,7 +95,7 @@ __device__ inline void r16_decode1(R16Lds &sm, int line, int k)
     const int wd = r16_word<DIR>(line), sh = 16 * r16_half<DIR>(line);
 #pragma unroll
     for (int b = 0; b < 8; b++) {
-        const unsigned c = (sm.hist[(8 * G + b) * 32 + wd] >> sh) & 0xFFFFu;
+        const unsigned c = (sm.hist[(8 * G + b) * R16_WORDS + wd] >> sh) & 0xFFFFu;
         const bool take = (B < 0) & ((int)(cum + c) >= k);
         B = take ? 8 * G + b : B;
         cb = take ? cum : cb;
@@ -119,8 +133,9 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
     bool ok = (d1 != 0x7FFFFFFFu) & (sm.ovf_n <= (unsigned)R16_OVF) & (B > 0);
     const int sstar = (int)(d1 & 15u), r = (int)((d1 >> 8) & 0xFFFu), cums = (int)(d1 >> 20) & 0xFFF;
     const int fq = line >> 2, fs = 8 * (line & 3);
-    const unsigned *fbase = sm.fine + (16 * sstar) * 16 + fq;        // x = 16 sstar + i
-    const int f = (int)((fbase[(1 + e) * 16] >> fs) & 0xFFu);       // this lane: x = 16 sstar + 1 + e
+    constexpr int FW = R16_LINES / 4;
+    const unsigned *fbase = sm.fine + (16 * sstar) * FW + fq;        // x = 16 sstar + i
+    const int f = (int)((fbase[(1 + e) * FW] >> fs) & 0xFFu);       // this lane: x = 16 sstar + 1 + e
     const int incl2 = r16_row_scan(f);
     const bool mine = ok & (incl2 - f < r) & (r <= incl2);           // one lane of the sixteen
     unsigned t1 = 0;
@@ -136,7 +151,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         hlo_x = (int)h_lo - w0;
         hhi_x = (int)h_hi - w0;
         good = good & (hlo_x >= thx - 1) & (hlo_x <= thx) & (hhi_x >= thx) & (hhi_x <= thx + 1);
-        const int c_m1 = (int)((fbase[e * 16] >> fs) & 0xFFu), c_p1 = (int)((fbase[(2 + e) * 16] >> fs) & 0xFFu);
+        const int c_m1 = (int)((fbase[e * FW] >> fs) & 0xFFu), c_p1 = (int)((fbase[(2 + e) * FW] >> fs) & 0xFFu);
         const int above = hhi_x > thx ? c_p1 : 0, in_lo = hlo_x < thx ? c_m1 : 0;
         if (good & (cle == k) & (above == 0)) t1 = th16 + 1u;
         else if (good) {
@@ -196,12 +211,12 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         };
 #pragma unroll
         for (int o = e; o < (DIR ? 32 : 16); o += 16) {
-            const int owner = DIR ? (line >> 1) + 32 * o : 64 * (4 * (line >> 4) + (o & 3)) + (line & 15) + 16 * (o >> 2);
+            const int owner = DIR ? (line >> 1) + R16_WORDS * o : 64 * (4 * (line >> 4) + (o & 3)) + (line & 15) + 16 * (o >> 2);
             const int h = (int)hcnt[owner];
             for (int q = 0; q < h; q++) take(sm.hist[q * R16_THREADS + owner]);
         }
         const int n_ovf = (int)min(sm.ovf_n, (unsigned)R16_OVF);
-        for (int o = e; o < n_ovf; o += 16) take(sm.S[1024 + o]);
+        for (int o = e; o < n_ovf; o += 16) take(sm.S[R16_THREADS + o]);
     }
 }
 
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
     // ---- the tile's keys: 32 dwords per thread, every load in flight before the first is used
     unsigned wv[32];
-    const int pi = t & 31, rs = t >> 5;                     // columns
+    const int pi = t & (R16_WORDS - 1), rs = t / R16_WORDS;   // columns (rs: 0 .. 31)
     const int wave = t >> 6;
     const int rr = 16 * (wave >> 2) + (lane & 15), jj = (lane >> 4) + 4 * (wave & 3);      // rows
     if (DIR == 1) {
@@ -254,7 +269,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const uint16_t *base = keys + ds.crp_off + min(c0, max(ds.crp_pitch - 2, 0)) + (int64_t)rs * ds.crp_pitch;
 #pragma unroll
             for (int q = 0; q < 32; q++)
-                wv[q] = rs + 32 * q < M ? __builtin_nontemporal_load(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
+                wv[q] = rs + 32 * q < M ? R16_COL_LOAD(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
         } else {
             const bool ha = c0 < ds.crp_pitch, hb = c0 + 1 < ds.crp_pitch;
             const uint16_t *base = keys + ds.crp_off + (ha ? c0 : 0) + (int64_t)rs * ds.crp_pitch;
@@ -311,10 +326,10 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         {
             uint4 *hz = reinterpret_cast<uint4 *>(sm.hist);
             hz[t] = make_uint4(0u, 0u, 0u, 0u);
-            hz[t + 1024] = make_uint4(0u, 0u, 0u, 0u);
+            hz[t + R16_THREADS] = make_uint4(0u, 0u, 0u, 0u);
             uint4 *fz = reinterpret_cast<uint4 *>(sm.fine);
             fz[t] = make_uint4(0u, 0u, 0u, 0u);
-            if (t < (int)(sizeof(sm.fine) / 16) - 1024) fz[t + 1024] = make_uint4(0u, 0u, 0u, 0u);
+            if (t < (int)(sizeof(sm.fine) / 16) - R16_THREADS) fz[t + R16_THREADS] = make_uint4(0u, 0u, 0u, 0u);
             sm.sub[t] = 0u;
             if (t == 0) { sm.ovf_n = 0u; sm.item_n = 0u; }
             if (t < R16_LINES) { sm.dec[t] = 0x7FFFFFFFu; sm.rcnt[t] = 0u; }
@@ -322,12 +337,12 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         lds_barrier();
         // ---- pass 1: histogram over the high bytes
         {
-            const unsigned lanebase = r16_lds_off(sm.hist) + 4u * (unsigned)(DIR ? pi : (rr & 31));
-            const unsigned vlo = DIR ? 1u : (rr < 32 ? 1u : 0x10000u), vhi = DIR ? 0x10000u : vlo;
+            const unsigned lanebase = r16_lds_off(sm.hist) + 4u * (unsigned)(DIR ? pi : (rr & (R16_WORDS - 1)));
+            const unsigned vlo = DIR ? 1u : (rr < R16_WORDS ? 1u : 0x10000u), vhi = DIR ? 0x10000u : vlo;
             auto bin = [&](const int q) {
                 const unsigned x = wv[q];
-                r16_lds_add(lanebase + ((x >> 1) & 0x7F80u), vlo);
-                r16_lds_add(lanebase + ((x >> 17) & 0x7F80u), vhi);
+                r16_lds_add(lanebase + ((x >> R16_BINSHIFT) & R16_BINMASK), vlo);
+                r16_lds_add(lanebase + ((x >> (16 + R16_BINSHIFT)) & R16_BINMASK), vhi);
             };
             if (q_end == 32) {                              // (block-uniform: the full-size form has no tests inside)
 #pragma unroll
@@ -344,15 +359,15 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         {
             unsigned s = 0;
 #pragma unroll
-            for (int b = 0; b < 8; b++) s += sm.hist[(8 * rs + b) * 32 + pi];
+            for (int b = 0; b < 8; b++) s += sm.hist[(8 * rs + b) * R16_WORDS + pi];
             unsigned *S = sm.S;
             S[rs * R16_LINES + (DIR ? 2 * pi : pi)] = s & 0xFFFFu;
-            S[rs * R16_LINES + (DIR ? 2 * pi + 1 : pi + 32)] = s >> 16;
+            S[rs * R16_LINES + (DIR ? 2 * pi + 1 : pi + R16_WORDS)] = s >> 16;
         }
         lds_barrier();
         if (t < R16_LINES) r16_decode1<DIR>(sm, t, k);
         lds_barrier();
-        if (dbg == 3) { if (sm.lineB[t & 63] == 0x12345678) t1_out[0] = 1; return; }
+        if (dbg == 3) { if (sm.lineB[t & (R16_LINES - 1)] == 0x12345678) t1_out[0] = 1; return; }
         // ---- pass 2: the keys inside each line's window: counted by sixteens and by key, listed with their positions
         {
             const int la = DIR ? 2 * pi : rr, lb2 = DIR ? 2 * pi + 1 : rr;
@@ -368,13 +383,13 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             auto count = [&](const unsigned rec) {
                 const unsigned x = rec & 0x1FFu, line = rec >> 19;
                 if (x - 1u < 256u) atomicAdd(&sm.sub[((x - 1u) >> 4) * R16_LINES + line], 1u);
-                atomicAdd(&sm.fine[x * 16 + (line >> 2)], 1u << (8 * (line & 3)));
+                atomicAdd(&sm.fine[x * (R16_LINES / 4) + (line >> 2)], 1u << (8 * (line & 3)));
             };
             auto hit = [&](const unsigned rec) {
                 if (hc < (unsigned)R16_SLOTS) *(r16_lds_word *)(uintptr_t)(slotbase + hc * (4u * R16_THREADS)) = rec;
                 else {
                     const unsigned oi = atomicAdd(&sm.ovf_n, 1u);
-                    if (oi < (unsigned)R16_OVF) sm.S[1024 + oi] = rec;
+                    if (oi < (unsigned)R16_OVF) sm.S[R16_THREADS + oi] = rec;
                     count(rec);
                 }
                 hc++;
@@ -447,7 +462,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             mb[rr * 144 + piece] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);        // (144: the sixteen rows of a wave instruction meet two to a bank)
         }
         lds_barrier();
-        if (t < 512 && l0 + (t >> 3) < M)
+        if (t < 8 * R16_LINES && l0 + (t >> 3) < M)
             reinterpret_cast<uint4 *>(bits)[((int64_t)p * w.max_m + l0) * 8 + t] = reinterpret_cast<const uint4 *>(mb)[(t >> 3) * 9 + (t & 7)];
     }
 }
@@ -539,8 +554,8 @@ __global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restric
         if (w.pair_flag[p]) continue;
         R16Item *items = w.items + (int64_t)R16_TILE_ITEMS * tile;
         const uint4 *src = reinterpret_cast<const uint4 *>(items);
-        sm.rec[lane] = src[lane];
-        if (lane < R16_TILE_ITEMS * 10 - 64) sm.rec[64 + lane] = src[64 + lane];
+        if (lane < R16_TILE_ITEMS * 10) sm.rec[lane] = src[lane];
+        if (lane + 64 < R16_TILE_ITEMS * 10) sm.rec[64 + lane] = src[64 + lane];
         const acoss_pair_desc ds = descs[p];
         __syncthreads();
         // the tile's cells, item after item

@@ -10,6 +10,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth, _lib
 
 args = sys.argv[1:]
+for a in list(args):                    # lib=path: another build of the library (tools/build_variant.py)
+    if a.startswith("lib="):
+        _lib.LIB_PATH = os.path.abspath(a[4:])
+        args.remove(a)
 K = int(args[0]) if args and args[0].isdigit() else 4096
 ragged = "ragged" in args
 lib = _lib.load()
