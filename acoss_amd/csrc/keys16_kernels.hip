@@ -516,7 +516,8 @@ static bool radix16_enabled()
     if (e == nullptr) return true;
     return !(e[0] == 0 || strcmp(e, "0") == 0 || strcmp(e, "false") == 0 || strcmp(e, "no") == 0);
 }
-constexpr int K16_LIST_SLOTS = 8;          // pairs the list kernels cover at a time
+constexpr int K16_LIST_SLOTS = 128;        // pairs the list kernels cover at a time (their blocks find the list empty on the benchmark's data;
+                                           // corpora with repeated frames hand back a fifth of their pairs)
 
 }  // namespace acoss
 
@@ -631,6 +632,21 @@ extern "C" int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const fl
 {
     return mask_bits_keys16_impl<float>(keys16, band, koff, xp, f32, n32, f32, n32, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits,
                                         work, work_bytes, stream);
+}
+
+// What the last acoss_mask_bits_keys16(_f32)_batch call on this workspace did (synchronises with the device; tests and tools):
+// out[0] work items beyond the tiles' own slots, out[1] rows + columns that flagged their pair, out[2] pairs handed to the
+// wave-per-row kernels, out[3] reserved; out[8 .. 19]: why lines flagged their pair (radix16_kernels.hip).  out: 20 ints.
+extern "C" int acoss_mask_bits_keys16_stats(void *work, int K, int max_nx, int max_ny, int win, int *out)
+{
+    if (!work || !out || K <= 0) { set_error("mask_bits_keys16_stats: bad argument"); return ACOSS_EINVAL; }
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    const ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    if (w.radix == nullptr) { set_error("mask_bits_keys16_stats: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
+    const R16Work rw = r16_work_layout(w.radix, K, max_m, max_n);
+    ACOSS_HIP(hipDeviceSynchronize());
+    ACOSS_HIP(hipMemcpy(out, rw.counters, 20 * sizeof(int), hipMemcpyDeviceToHost));
+    return ACOSS_OK;
 }
 
 // koff[pair] for acoss_crp_keys16_batch / acoss_mask_bits_keys16_f32_batch on a float32 corpus (k16_koff_pair_kernel: the key

@@ -16,8 +16,7 @@
 
 namespace acoss {
 
-constexpr int R16_CAP = 64;              // cells a row / column may hold inside its captured key window
-constexpr int R16_LS = R16_CAP + 1;      // list stride in LDS words (odd: neighbouring lists start in different banks)
+constexpr int R16_CAP = 24;              // cells in reach an item can hold (2-4 on the benchmark; more: exact ties, the pair is handed back)
 
 struct __attribute__((aligned(16))) R16Item {
     int p, dir, which, need;
@@ -25,7 +24,7 @@ struct __attribute__((aligned(16))) R16Item {
     unsigned sel_lo, sel_hi;             // bit m: cell pos[m] is selected (r16_exact_kernel)
     int reserved;
     uint16_t pos[R16_CAP];
-};                                        // 160 bytes
+};                                        // 80 bytes
 
 struct R16Work {
     uint16_t *t1_row, *t1_col;           // [K][max_m], [K][max_n]

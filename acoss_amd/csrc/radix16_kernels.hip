@@ -64,11 +64,12 @@ struct R16Lds {
     unsigned t1[R16_LINES];
     unsigned dec[R16_LINES], rcnt[R16_LINES];
     int ditem[R16_LINES];
-    unsigned ovf_n, item_n;
+    unsigned sweep3, item_n;
     uint4 tcol[128];                           // row kernel: the pair's column bounds
 };
-constexpr int R16_SLOTS = 8;                   // hits a thread can hold (x | position << 9 | line << 19 each); further ones go to
-constexpr int R16_OVF = 32 * R16_TILE_LINES - 16 * R16_TILE_LINES;      // the block's overflow list: the part of S behind hcnt[thread]
+constexpr int R16_SLOTS = 8;                   // hits a thread can hold (x | position << 9 | line << 19 each).  A thread with more
+                                               // (temporally smooth features: runs of neighbouring cells inside one window) still
+                                               // COUNTS them all; the block then finds the items' cells by a third sweep
 
 template <int DIR> __device__ inline int r16_word(int line) { return DIR ? line >> 1 : line & (R16_WORDS - 1); }
 template <int DIR> __device__ inline int r16_half(int line) { return DIR ? line & 1 : line / R16_WORDS; }
@@ -130,13 +131,16 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
     if ((incl - c < need) & (need <= incl)) sm.dec[line] = (unsigned)e | ((unsigned)(need - (incl - c)) << 8) | ((unsigned)(incl - c) << 20);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned d1 = sm.dec[line];
-    bool ok = (d1 != 0x7FFFFFFFu) & (sm.ovf_n <= (unsigned)R16_OVF) & (B > 0);
+    bool ok = (d1 != 0x7FFFFFFFu) & (B > 0);
     const int sstar = (int)(d1 & 15u), r = (int)((d1 >> 8) & 0xFFFu), cums = (int)(d1 >> 20) & 0xFFF;
     const int fq = line >> 2, fs = 8 * (line & 3);
     constexpr int FW = R16_LINES / 4;
     const unsigned *fbase = sm.fine + (16 * sstar) * FW + fq;        // x = 16 sstar + i
     const int f = (int)((fbase[(1 + e) * FW] >> fs) & 0xFFu);       // this lane: x = 16 sstar + 1 + e
     const int incl2 = r16_row_scan(f);
+    // (the counts by key are bytes, four lines to a word: 256 equal keys in one line would carry into its neighbour -- then the
+    //  sixteen counts no longer add up to the count of their sixteen, in either line)
+    const int total16 = __shfl(incl2, (threadIdx.x & 48) + 15, 64);
     const bool mine = ok & (incl2 - f < r) & (r <= incl2);           // one lane of the sixteen
     unsigned t1 = 0;
     int item = -1, hlo_x = 0, hhi_x = -1;
@@ -145,12 +149,14 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         const int cle = cb + cums + incl2;                 // keys <= the threshold key
         const int w0 = 256 * B - 1;                        // the key of x == 0
         const unsigned th16 = (unsigned)(w0 + thx);
-        bool good = th16 < K16_MAX;
+        int why = th16 < K16_MAX ? 0 : 1;
+        if (total16 != (int)sm.sub[sstar * R16_LINES + line]) why = 2;
+        bool good = why == 0;
         unsigned h_lo = 0, h_hi = 0;
         k16_reach(good ? th16 : (K16_FINE + 1u), koff, adjacent_ok, pair_band, h_lo, h_hi);
         hlo_x = (int)h_lo - w0;
         hhi_x = (int)h_hi - w0;
-        good = good & (hlo_x >= thx - 1) & (hlo_x <= thx) & (hhi_x >= thx) & (hhi_x <= thx + 1);
+        if (good & !((hlo_x >= thx - 1) & (hlo_x <= thx) & (hhi_x >= thx) & (hhi_x <= thx + 1))) { good = false; why = 3; }
         const int c_m1 = (int)((fbase[e * FW] >> fs) & 0xFFu), c_p1 = (int)((fbase[(2 + e) * FW] >> fs) & 0xFFu);
         const int above = hhi_x > thx ? c_p1 : 0, in_lo = hlo_x < thx ? c_m1 : 0;
         if (good & (cle == k) & (above == 0)) t1 = th16 + 1u;
@@ -158,6 +164,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
             // the cells in reach decide by exact value: those below the reach are selected, `need2` of the reach's cells too
             const int nR = in_lo + f + above, below = cle - f - in_lo, need2 = k - below;
             good = (need2 >= 1) & (need2 <= nR) & (nR <= R16_CAP);
+            if (!good) why = nR > R16_CAP ? 4 : 5;
             if (good) {
                 t1 = h_lo;
                 if (valid && dbg != 8) {
@@ -165,7 +172,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
                     if (li < R16_TILE_ITEMS) item = item0 + li;
                     else {
                         item = w.static_items + atomicAdd(&w.counters[0], 1);
-                        if (item >= w.item_cap) { item = -1; good = false; }
+                        if (item >= w.item_cap) { item = -1; good = false; why = 6; }
                     }
                     if (item >= 0) {
                         R16Item *it = w.items + item;
@@ -183,6 +190,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
             if (!good) {
                 w.pair_flag[p] = 1;
                 atomicAdd(&w.counters[1], 1);
+                atomicAdd(&w.counters[8 + why], 1);           // statistics: [9] key at the top, [10] byte counts, [11] reach, [12] ties, [13] need, [14] items
             }
             t1_out[which] = (uint16_t)t1;
             item_out[which] = item;
@@ -193,11 +201,11 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
     if (!(d2 & 0x80000000u)) {                              // no lane found the key (counts that do not add up: cannot happen)
         if (e == 0) {
             sm.t1[line] = 0u;
-            if (valid) { w.pair_flag[p] = 1; t1_out[which] = 0; item_out[which] = -1; }
+            if (valid) { w.pair_flag[p] = 1; atomicAdd(&w.counters[1], 1); atomicAdd(&w.counters[B > 0 ? 15 : 16], 1); t1_out[which] = 0; item_out[which] = -1; }
         }
         return;
     }
-    if (d2 & 1u) {
+    if ((d2 & 1u) && sm.sweep3 == 0u) {
         // the item's cells: lane e looks through the hits of the threads e (and e + 16) that hold keys of the line
         const int lo = (int)((d2 >> 1) & 0x1FFu), hi = (int)((d2 >> 10) & 0x1FFu);
         R16Item *it = w.items + sm.ditem[line];
@@ -215,8 +223,6 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
             const int h = (int)hcnt[owner];
             for (int q = 0; q < h; q++) take(sm.hist[q * R16_THREADS + owner]);
         }
-        const int n_ovf = (int)min(sm.ovf_n, (unsigned)R16_OVF);
-        for (int o = e; o < n_ovf; o += 16) take(sm.S[R16_THREADS + o]);
     }
 }
 
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             fz[t] = make_uint4(0u, 0u, 0u, 0u);
             if (t < (int)(sizeof(sm.fine) / 16) - R16_THREADS) fz[t + R16_THREADS] = make_uint4(0u, 0u, 0u, 0u);
             sm.sub[t] = 0u;
-            if (t == 0) { sm.ovf_n = 0u; sm.item_n = 0u; }
+            if (t == 0) { sm.sweep3 = 0u; sm.item_n = 0u; }
             if (t < R16_LINES) { sm.dec[t] = 0x7FFFFFFFu; sm.rcnt[t] = 0u; }
         }
         lds_barrier();
@@ -388,9 +394,8 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             auto hit = [&](const unsigned rec) {
                 if (hc < (unsigned)R16_SLOTS) *(r16_lds_word *)(uintptr_t)(slotbase + hc * (4u * R16_THREADS)) = rec;
                 else {
-                    const unsigned oi = atomicAdd(&sm.ovf_n, 1u);
-                    if (oi < (unsigned)R16_OVF) sm.S[R16_THREADS + oi] = rec;
                     count(rec);
+                    sm.sweep3 = 1u;
                 }
                 hc++;
             };
@@ -429,6 +434,33 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                              pair_band, w, t1_out, item_out, dbg);
             lds_barrier();
             if (t == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = (int)min(sm.item_n, (unsigned)R16_TILE_ITEMS);
+        }
+        // ---- sweep 3, only in a block where some thread had more hits than slots: the items' cells straight from the registers
+        if (sm.sweep3 != 0u) {
+            const int la = DIR ? 2 * pi : rr, lb2 = DIR ? 2 * pi + 1 : rr;
+            const unsigned b0 = (unsigned)(256 * sm.lineB[la] - 1) & 0xFFFFu, b1 = (unsigned)(256 * sm.lineB[lb2] - 1) & 0xFFFFu;
+            const u16x2 bsh = k16_from_u32(b0 | (b1 << 16));
+            const unsigned da = sm.dec[la], db = sm.dec[lb2];
+            const bool ha = (da & 0x80000001u) == 0x80000001u, hb = (db & 0x80000001u) == 0x80000001u;
+            const unsigned lo_a = (da >> 1) & 0x1FFu, lo_b = (db >> 1) & 0x1FFu;
+            const unsigned wid_a = ha ? ((da >> 10) & 0x1FFu) - lo_a + 1u : 0u, wid_b = hb ? ((db >> 10) & 0x1FFu) - lo_b + 1u : 0u;
+            R16Item *ia = w.items + (ha ? sm.ditem[la] : 0), *ib = w.items + (hb ? sm.ditem[lb2] : 0);
+#pragma unroll
+            for (int q = 0; q < 32; q++) {
+                if (q < q_end) {
+                    const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
+                    const unsigned xl = x & 0xFFFFu, xh = x >> 16;
+                    const unsigned pos = DIR ? (unsigned)(rs + 32 * q) : (unsigned)(8 * (jj + 16 * (q >> 2)) + 2 * (q & 3));
+                    if (xl - lo_a < wid_a) {
+                        const unsigned slot = atomicAdd(&sm.rcnt[la], 1u);
+                        if (slot < (unsigned)R16_CAP) ia->pos[slot] = (uint16_t)pos;
+                    }
+                    if (xh - lo_b < wid_b) {
+                        const unsigned slot = atomicAdd(&sm.rcnt[lb2], 1u);
+                        if (slot < (unsigned)R16_CAP) ib->pos[slot] = (uint16_t)(DIR ? pos : pos + 1u);
+                    }
+                }
+            }
         }
     } else {                                                // (rows only)
         if (t < R16_LINES) {
@@ -499,9 +531,9 @@ __device__ inline void r16_exact_term(const FT *__restrict__ feats, const FT *__
 
 struct R16ExactSmem {
     double cval[64];
-    unsigned long long key[R16_CAP];
-    int posv[R16_CAP], citem[R16_CAP];
-    uint4 rec[R16_TILE_ITEMS * 10];              // a tile's item records
+    unsigned long long key[64];
+    int posv[64], citem[64];
+    uint4 rec[R16_TILE_ITEMS * 5];               // a tile's item records (80 bytes each)
 };
 
 // one item, the wave together (items with more than a handful of cells, and the items behind the tiles' own slots)
@@ -554,15 +586,15 @@ __global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restric
         if (w.pair_flag[p]) continue;
         R16Item *items = w.items + (int64_t)R16_TILE_ITEMS * tile;
         const uint4 *src = reinterpret_cast<const uint4 *>(items);
-        if (lane < R16_TILE_ITEMS * 10) sm.rec[lane] = src[lane];
-        if (lane + 64 < R16_TILE_ITEMS * 10) sm.rec[64 + lane] = src[64 + lane];
+        static_assert(R16_TILE_ITEMS * 5 <= 64, "one load per lane");
+        if (lane < R16_TILE_ITEMS * 5) sm.rec[lane] = src[lane];
         const acoss_pair_desc ds = descs[p];
         __syncthreads();
         // the tile's cells, item after item
         int start = 0, mine = -1, n_mine = 0, total = 0;
 #pragma unroll
         for (int l = 0; l < R16_TILE_ITEMS; l++) {
-            const int nl = l < used ? min((int)sm.rec[10 * l + 1].x, R16_CAP) : 0;
+            const int nl = l < used ? min((int)sm.rec[5 * l + 1].x, R16_CAP) : 0;
             if (lane >= total && lane < total + nl) { mine = l; start = total; n_mine = nl; }
             total += nl;
         }
@@ -572,14 +604,14 @@ __global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restric
         }
         if (mine >= 0) {
             sm.citem[lane] = mine;
-            sm.posv[lane] = (int)reinterpret_cast<const uint16_t *>(&sm.rec[10 * mine + 2])[lane - start];
+            sm.posv[lane] = (int)reinterpret_cast<const uint16_t *>(&sm.rec[5 * mine + 2])[lane - start];
         }
         __syncthreads();
         for (int e0 = 0; e0 < total; e0 += 7) {
             const int g = lane / 9, kk = lane - 9 * g, el = e0 + g;
             if (lane < 63 && el < total) {
                 const int l = sm.citem[el];
-                const uint4 hdr = sm.rec[10 * l];
+                const uint4 hdr = sm.rec[5 * l];
                 r16_exact_term<FT>(feats, norms, d, ds, hdr.y == 0u, (int)hdr.z, sm.posv[el], kk, &sm.cval[g * 9 + kk]);
             }
             __syncthreads();
@@ -593,7 +625,7 @@ __global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restric
         bool sel = false;
         if (mine >= 0) {
             const unsigned long long mykey = sm.key[lane];
-            const int mypos = sm.posv[lane], need = (int)sm.rec[10 * mine].w;
+            const int mypos = sm.posv[lane], need = (int)sm.rec[5 * mine].w;
             int rank = 1;
             for (int m = start; m < start + n_mine; m++) {
                 const unsigned long long km = sm.key[m];
@@ -609,7 +641,7 @@ __global__ __launch_bounds__(64) void r16_exact_tiles_kernel(const FT *__restric
             unsigned long long m_l = 0;
 #pragma unroll
             for (int l = 0; l < R16_TILE_ITEMS; l++) {
-                const int nl = l < used ? min((int)sm.rec[10 * l + 1].x, R16_CAP) : 0;
+                const int nl = l < used ? min((int)sm.rec[5 * l + 1].x, R16_CAP) : 0;
                 if (l == lane) m_l = nl >= 64 ? all : ((all >> st) & ((1ull << nl) - 1ull));
                 st += nl;
             }

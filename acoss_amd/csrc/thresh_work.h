@@ -36,14 +36,15 @@ struct ThreshWork {
 };
 
 // ---- workspace of the radix selection (radix16.h lays it out; up to 1024 x 1024 only): behind the side buffer ---------------------
-// Every tile of 64 lines owns R16_TILE_ITEMS item slots (no global atomic on the selection kernels' path; 2.5 of a tile's lines
-// need an item on the benchmark); a tile with more asks for single items behind them: room for 2 % of the lines.
+// Every tile of lines owns R16_TILE_ITEMS item slots, one for four lines (no global atomic on the selection kernels' path; 4 % of
+// the lines need an item on the benchmark, 15-25 % on temporally smooth features); a tile with more asks for single items behind
+// them: room for 2 % of the lines.
 #ifndef R16_TILE_LINES_V
 #define R16_TILE_LINES_V 32              // lines (rows or columns) per block of the selection kernel: 32 (eight waves, four blocks per CU: measured 4.1 ms per 4096 pairs against 4.8) or 64 (sixteen)
 #endif
 constexpr int R16_TILE_LINES = R16_TILE_LINES_V;
-constexpr int R16_TILE_ITEMS = R16_TILE_LINES / 8;
-constexpr size_t R16_ITEM_BYTES = 160;
+constexpr int R16_TILE_ITEMS = R16_TILE_LINES / 4;
+constexpr size_t R16_ITEM_BYTES = 80;
 
 inline int r16_tiles(int K, int max_m, int max_n) { return K * ((max_m + R16_TILE_LINES - 1) / R16_TILE_LINES + (max_n + R16_TILE_LINES - 1) / R16_TILE_LINES); }
 

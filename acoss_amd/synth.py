@@ -54,7 +54,22 @@ def _global_chroma(chroma):
     return np.divide(s, np.max(s))
 
 
-def _base_song(rng, n_frames, nbins):
+def _ar1(rng, shape, scale, rho):
+    """Noise with the marginal spread of U(0, scale) that is correlated from frame to frame: an AR(1) sequence per bin,
+    e_t = rho e_{t-1} + sqrt(1 - rho^2) u_t with u_t = U(0, scale) - scale / 2, shifted back to mean scale / 2.  rho = 0: U(0, scale) itself."""
+    u = rng.uniform(0.0, scale, size=shape)
+    if rho <= 0.0:
+        return u
+    u -= 0.5 * scale
+    e = np.empty(shape)
+    e[0] = u[0]
+    g = np.sqrt(1.0 - rho * rho)
+    for t in range(1, shape[0]):
+        e[t] = rho * e[t - 1] + g * u[t]
+    return e + 0.5 * scale
+
+
+def _base_song(rng, n_frames, nbins, rho=0.0):
     base = np.zeros((n_frames, nbins))
     pos = 0
     while pos < n_frames:
@@ -65,11 +80,11 @@ def _base_song(rng, n_frames, nbins):
         template[bins] = rng.uniform(0.5, 1.0, size=n_active)
         base[pos:pos + seg] = template[None, :]
         pos += seg
-    base += rng.uniform(0.0, 0.15, size=base.shape)
+    base += np.clip(_ar1(rng, base.shape, 0.15, rho), 0.0, None)
     return base
 
 
-def _version(rng, base, n_frames, noise=0.2, tempo_range=(0.8, 1.25)):
+def _version(rng, base, n_frames, noise=0.2, tempo_range=(0.8, 1.25), rho=0.0):
     nbins = base.shape[1]
     shift = int(rng.integers(0, nbins))
     tempo = rng.uniform(tempo_range[0], tempo_range[1])
@@ -79,14 +94,14 @@ def _version(rng, base, n_frames, noise=0.2, tempo_range=(0.8, 1.25)):
     frac = (src - lo)[:, None]
     x = (1.0 - frac) * base[lo] + frac * base[lo + 1]
     x = np.roll(x, shift, axis=1)
-    x = x + rng.uniform(0.0, noise, size=x.shape)
+    x = x + _ar1(rng, x.shape, noise, rho)
     x = np.clip(x, 0.0, None)
     x = x / np.max(x, axis=1, keepdims=True)
     return np.ascontiguousarray(x, dtype=np.float64)
 
 
 def make_corpus(n_cliques, versions, n_frames=1000, nbins=12, seed=20260, lengths=None,
-                singletons=0, noise=0.2, tempo_range=(0.8, 1.25)):
+                singletons=0, noise=0.2, tempo_range=(0.8, 1.25), rho=0.0):
     """
     Parameters
     ----------
@@ -104,10 +119,10 @@ def make_corpus(n_cliques, versions, n_frames=1000, nbins=12, seed=20260, length
     songs, labels = [], []
     sizes = [versions] * n_cliques + [1] * singletons
     for c, size in enumerate(sizes):
-        base = _base_song(rng, 1000 if lengths is not None else max(n_frames, 32), nbins)
+        base = _base_song(rng, 1000 if lengths is not None else max(n_frames, 32), nbins, rho)
         for _ in range(size):
             n = int(lengths(rng)) if lengths is not None else n_frames
-            songs.append(_version(rng, base, n, noise, tempo_range))
+            songs.append(_version(rng, base, n, noise, tempo_range, rho))
             labels.append("clique_%05d" % c)
     frame_off = np.zeros(len(songs) + 1, dtype=np.int64)
     frame_off[1:] = np.cumsum([s.shape[0] for s in songs])
@@ -119,6 +134,13 @@ def make_corpus(n_cliques, versions, n_frames=1000, nbins=12, seed=20260, length
 def config2(n_songs=1000, n_frames=1000, seed=20260):
     """BASELINE config 2: 1k songs x 1000-frame 12-bin HPCP, 250 cliques x 4."""
     return make_corpus(n_songs // 4, 4, n_frames=n_frames, seed=seed)
+
+
+def config2_smooth(n_songs=1000, n_frames=1000, seed=20262, rho=0.9):
+    """Config 2's shape with TEMPORALLY SMOOTH frames: the per-frame noise of the base songs and of the versions is an AR(1)
+    sequence (rho = 0.9) instead of independent draws -- what real HPCP / crema frames look like from one frame to the next.
+    (rho > 0 changes the random stream, so this is its own corpus, not config2() smoothed.)"""
+    return make_corpus(n_songs // 4, 4, n_frames=n_frames, seed=seed, rho=rho)
 
 
 def config2_hard(n_songs=64, n_frames=1000, seed=20261, noise=HARD_NOISE, tempo_range=HARD_TEMPO):

@@ -326,6 +326,10 @@ int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, 
                                      const float *f32, const float *n32, int d, const acoss_pair_desc *descs, int K, int win,
                                      int max_nx, int max_ny, double kappa, int mutual, uint64_t *bits, void *work,
                                      size_t work_bytes, void *stream);
+/* What the last acoss_mask_bits_keys16(_f32)_batch call on `work` did (synchronises with the device; tests and tools): out[0]
+ * work items beyond the tiles' own slots, out[1] rows + columns that flagged their pair, out[2] pairs handed to the
+ * wave-per-row kernels, out[3] reserved, out[8 .. 19] why lines flagged their pair (development statistics).  out: 20 ints. */
+int acoss_mask_bits_keys16_stats(void *work, int K, int max_nx, int max_ny, int win, int *out);
 /* Round 5: the selection of acoss_mask_bits_keys16_batch as a two-pass radix selection with the keys in registers
  * (csrc/radix16_kernels.hip) -- the form acoss_mask_bits_keys16_batch itself runs; these are its stages, exposed for the
  * per-kernel measurements of bench.py and the stage tests.  `what` is a bit set: 1 = the column kernel (every column's bound

@@ -22,6 +22,14 @@ xp32 = engine.pack_x32(corpus, batch)
 koff = engine.keys16_koff_f32(corpus, batch, xp32); band = engine.keys16_band_f32(corpus, batch)
 k16 = engine.crp_keys16(corpus, batch, xp32, koff)
 bits, work = engine.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095)
+import ctypes
+st = (ctypes.c_int * 20)()
+engine._lib.load().acoss_mask_bits_keys16_stats(engine._ptr(work), batch.K, batch.max_nx, batch.max_ny, 9, st)
+print("radix stats: extra items %d, flagged lines %d, flagged pairs %d of %d; reasons %s" % (st[0], st[1], st[2], batch.K, list(st[8:18])))
+for env in ("1", "0"):
+    os.environ["ACOSS_RADIX16"] = env
+    print("ACOSS_RADIX16=%s mask %.3f ms" % (env, t(lambda: engine.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, True, out=bits, work=work))))
+os.environ["ACOSS_RADIX16"] = "1"
 print("koff   %.3f ms" % t(lambda: engine.keys16_koff_f32(corpus, batch, xp32)))
 print("strip  %.3f ms" % t(lambda: engine.crp_keys16(corpus, batch, xp32, koff, out=k16)))
 print("rows   %.3f ms" % t(lambda: engine.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, "rows_kernel_only", out=bits, work=work)))

@@ -16,9 +16,12 @@ for a in list(args):                    # lib=path: another build of the library
         args.remove(a)
 K = int(args[0]) if args and args[0].isdigit() else 4096
 ragged = "ragged" in args
+smooth = "smooth" in args
 lib = _lib.load()
 if ragged:
     ch = synth.make_corpus(40, 4, seed=7, lengths=lambda r: int(r.integers(60, 1033)))
+elif smooth:
+    ch = synth.config2_smooth(n_songs=1000 if K > 1000 else 64, n_frames=1000)
 else:
     ch = synth.config2(n_songs=1000 if K > 1000 else 64, n_frames=1000)
 corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
@@ -34,7 +37,9 @@ xp = engine.pack_x32(corpus, batch)
 koff = engine.keys16_koff(corpus, batch)
 band = engine.planar32_band(corpus, batch)
 keys = engine.crp_keys16(corpus, batch, xp, koff)
+os.environ["ACOSS_RADIX16"] = "0"
 bits, work = engine.mask_bits_keys16(keys, band, koff, xp, corpus, batch, 0.095)
+os.environ["ACOSS_RADIX16"] = "1"
 ref_bits = bits.clone()
 P = engine._ptr
 st = engine._stream
@@ -67,9 +72,17 @@ def stage(what, mutual=1):
 
 
 def old(mutual):
+    os.environ["ACOSS_RADIX16"] = "0"
     engine.check(lib.acoss_mask_bits_keys16_batch(P(keys), P(band), P(koff), P(xp), P(f32), P(n32), P(corpus.feats), P(corpus.norms),
                                                   corpus.d, P(batch.descs_dev), K, 9, batch.max_nx, batch.max_ny, 0.095, mutual, P(bits),
                                                   P(work), work.numel(), st()), "old")
+    os.environ["ACOSS_RADIX16"] = "1"
+
+
+def new_call():
+    engine.check(lib.acoss_mask_bits_keys16_batch(P(keys), P(band), P(koff), P(xp), P(f32), P(n32), P(corpus.feats), P(corpus.norms),
+                                                  corpus.d, P(batch.descs_dev), K, 9, batch.max_nx, batch.max_ny, 0.095, 1, P(bits),
+                                                  P(work), work.numel(), st()), "new")
 
 
 stage(7)
@@ -122,5 +135,10 @@ print("direct: list + exact %.3f, list + exact + apply + flags %.3f;  by differe
     timed(lambda: stage(4 | 64)), timed(lambda: stage(4)), timed(lambda: stage(7 | 64)) - tcr))
 print("ms per %d pairs:  radix cols %.3f  rows %.3f  exact+apply %.3f  all %.3f   | old rows %.3f cols %.3f mask_bits %.3f" % (
     K, tc, tcr - tc, tall - tcr, tall, timed(lambda: old(2)), timed(lambda: old(3)), timed(lambda: old(1))))
+print("whole call: radix %.3f  old %.3f" % (timed(new_call), timed(lambda: old(1))))
+new_call()
+stt = (ctypes.c_int * 20)()
+lib.acoss_mask_bits_keys16_stats(P(work), K, batch.max_nx, batch.max_ny, 9, stt)
+print("whole call stats: extra items %d, flagged lines %d, flagged pairs %d; reasons %s; masks equal %s" % (stt[0], stt[1], stt[2], list(stt[8:18]), bool(torch.equal(bits, ref_bits))))
 for dbg in (1, 2, 3, 4, 8, 5):
     print("phase cut %d: cols %.3f rows %.3f" % (dbg, timed(lambda: stage(1 | (dbg << 8))), timed(lambda: stage(3 | (dbg << 12))) - tc))

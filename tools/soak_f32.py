@@ -31,5 +31,6 @@ engine.serra09_scores(corpus, pairs[:2000], do_oti=False, want=("qmax", "dmax", 
 t0 = time.time(); a = engine.serra09_scores(corpus, pairs, do_oti=False, want=("qmax", "dmax", "swc")); t1 = time.time()
 b = engine.serra09_scores(corpus, pairs, do_oti=False, want=("qmax", "dmax", "swc"), approx32=False); t2 = time.time()
 bad = {k: int(np.sum(a[k] != b[k])) for k in a}
+st = (engine.ctypes.c_int * 4)() if hasattr(engine, "ctypes") else None
 print("%d songs, %d pairs: filter %.2f s, float32-input chain %.2f s, mismatches %s" % (S, len(pairs), t1 - t0, t2 - t1, bad))
 assert not any(bad.values())
