@@ -63,7 +63,7 @@ struct R16Lds {
     int lineB[R16_LINES], linecb[R16_LINES];
     unsigned t1[R16_LINES];
     unsigned dec[R16_LINES], rcnt[R16_LINES];
-    int ditem[R16_LINES];
+    int ditem[R16_LINES], nr[R16_LINES];
     unsigned sweep3, item_n;
     uint4 tcol[128];                           // row kernel: the pair's column bounds
 };
@@ -159,12 +159,14 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         if (good & !((hlo_x >= thx - 1) & (hlo_x <= thx) & (hhi_x >= thx) & (hhi_x <= thx + 1))) { good = false; why = 3; }
         const int c_m1 = (int)((fbase[e * FW] >> fs) & 0xFFu), c_p1 = (int)((fbase[(2 + e) * FW] >> fs) & 0xFFu);
         const int above = hhi_x > thx ? c_p1 : 0, in_lo = hlo_x < thx ? c_m1 : 0;
+        int nR_keep = 0;
         if (good & (cle == k) & (above == 0)) t1 = th16 + 1u;
         else if (good) {
             // the cells in reach decide by exact value: those below the reach are selected, `need2` of the reach's cells too
             const int nR = in_lo + f + above, below = cle - f - in_lo, need2 = k - below;
             good = (need2 >= 1) & (need2 <= nR) & (nR <= R16_CAP);
             if (!good) why = nR > R16_CAP ? 4 : 5;
+            nR_keep = nR;
             if (good) {
                 t1 = h_lo;
                 if (valid && dbg != 8) {
@@ -186,6 +188,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         sm.t1[line] = t1;
         sm.dec[line] = 0x80000000u | (unsigned)(item >= 0) | ((unsigned)(hlo_x & 0x1FF) << 1) | ((unsigned)(hhi_x & 0x1FF) << 10) | ((unsigned)good << 19);
         sm.ditem[line] = item;
+        sm.nr[line] = item >= 0 ? nR_keep : 0;
         if (valid) {
             if (!good) {
                 w.pair_flag[p] = 1;
@@ -214,7 +217,7 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
             const int x = (int)(rec & 0x1FFu);
             if (((int)(rec >> 19) == line) & (x >= lo) & (x <= hi)) {
                 const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
-                it->pos[slot & (R16_CAP - 1)] = (uint16_t)((rec >> 9) & 0x3FFu);
+                if (slot < (unsigned)R16_CAP) it->pos[slot] = (uint16_t)((rec >> 9) & 0x3FFu);
             }
         };
 #pragma unroll
@@ -462,6 +465,13 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                 }
             }
         }
+        // every item must have found exactly its cells (slots or third sweep): anything else hands the pair back
+        lds_barrier();
+        if (t < R16_LINES && sm.ditem[t] >= 0 && (int)sm.rcnt[t] != sm.nr[t]) {
+            w.pair_flag[p] = 1;
+            atomicAdd(&w.counters[1], 1);
+            atomicAdd(&w.counters[8 + 9], 1);
+        }
     } else {                                                // (rows only)
         if (t < R16_LINES) {
             sm.t1[t] = k <= 0 ? 0u : 0xFFFFu;
@@ -683,6 +693,7 @@ __global__ __launch_bounds__(64) void r16_apply_kernel(const uint16_t *__restric
         for (uint64_t rest = sel; rest != 0; rest &= rest - 1) {
             const int pos = (int)item->pos[__ffsll((unsigned long long)rest) - 1];
             const int i = dir == 0 ? which : pos, j = dir == 0 ? pos : which;
+            if (i >= ds.nx - 8 || j >= ds.ny - 8) continue;             // (cannot happen: positions come from the selection kernels)
             bool other = true;
             if (mutual) {
                 const unsigned key = keys[ds.crp_off + (int64_t)i * ds.crp_pitch + j];
