@@ -341,7 +341,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             if (t < (int)(sizeof(sm.fine) / 16) - R16_THREADS) fz[t + R16_THREADS] = make_uint4(0u, 0u, 0u, 0u);
             sm.sub[t] = 0u;
             if (t == 0) { sm.sweep3 = 0u; sm.item_n = 0u; }
-            if (t < R16_LINES) { sm.dec[t] = 0x7FFFFFFFu; sm.rcnt[t] = 0u; }
+            if (t < R16_LINES) { sm.dec[t] = 0x7FFFFFFFu; sm.rcnt[t] = 0u; sm.ditem[t] = -1; sm.nr[t] = 0; }
         }
         lds_barrier();
         // ---- pass 1: histogram over the high bytes
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         }
         // every item must have found exactly its cells (slots or third sweep): anything else hands the pair back
         lds_barrier();
-        if (t < R16_LINES && sm.ditem[t] >= 0 && (int)sm.rcnt[t] != sm.nr[t]) {
+        if (t < R16_LINES && l0 + t < n_lines && sm.ditem[t] >= 0 && (int)sm.rcnt[t] != sm.nr[t]) {
             w.pair_flag[p] = 1;
             atomicAdd(&w.counters[1], 1);
             atomicAdd(&w.counters[8 + 9], 1);
