@@ -183,7 +183,7 @@ class CoverAlgorithm(object):
                 self.Ds = {k: z[k] for k in z.files}
             self.get_all_clique_ids()
         else:
-            all_pairs = self._pair_list(symmetric)
+            from . import sharding
             rank, world, dist, sharded = 0, 1, None, False
             try:
                 import torch.distributed as dist
@@ -194,18 +194,23 @@ class CoverAlgorithm(object):
                     sharded = world > 1 or os.environ.get("ACOSS_FORCE_COLLECTIVE", "0") == "1"
             except ImportError:
                 dist = None
-            mine = np.arange(len(all_pairs))
-            if sharded:
-                from . import sharding
-                costs = self._pair_costs(all_pairs)
-                mine = sharding.shard_indices(costs, world, rank)
-            local = {s: np.zeros(len(mine)) for s in self.similarity_types}
+            # The pair list is an enumeration (:166-168): a rank takes every world-th POSITION and forms its own pairs from the
+            # positions in closed form, batch by batch (sharding.py, round 5).  No list of all pairs, no sort, on any rank.
+            K = sharding.n_pairs(self.N, symmetric)
+            n_mine = len(range(rank, K, world)) if sharded else K
+            local = {s: np.zeros(n_mine) for s in self.similarity_types}
             memmaps, self.do_memmaps = self.do_memmaps, False     # scatter once at the end instead
+            t_sim = 0.0
             try:
-                for lo in range(0, len(mine), batch_pairs):
-                    res = self.similarity(all_pairs[mine[lo:lo + batch_pairs]])
+                for lo in range(0, n_mine, batch_pairs):
+                    hi = min(lo + batch_pairs, n_mine)
+                    pos = (rank + world * np.arange(lo, hi, dtype=np.int64)) if sharded else np.arange(lo, hi, dtype=np.int64)
+                    pairs = sharding.pairs_of_positions(self.N, pos, symmetric)
+                    t0 = time.time()
+                    res = self.similarity(pairs)
+                    t_sim += time.time() - t0
                     for s in self.similarity_types:
-                        local[s][lo:lo + batch_pairs] = res[s]
+                        local[s][lo:hi] = res[s]
             finally:
                 self.do_memmaps = memmaps
             if not hasattr(self, "Ds"):
@@ -214,15 +219,15 @@ class CoverAlgorithm(object):
                 full = local[s]
                 if sharded:
                     import torch
-                    from . import sharding
                     dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
-                    full = sharding.gather_scores(torch.from_numpy(local[s]).to(dev), mine, len(all_pairs),
-                                                  index_of_rank=lambda r: sharding.shard_indices(costs, world, r),
-                                                  force_collective=True).cpu().numpy()
+                    full = sharding.gather_strided(torch.from_numpy(local[s]).to(dev), K, force_collective=True).cpu().numpy()
                 # a matrix kept from an earlier call starts from zero again: `Ds += Ds.T` below would otherwise add the new
                 # upper triangle to the old lower one (the reference's matrices are fresh 'w+' memmaps, CoverAlgorithm.py:52-55)
                 self.Ds[s][:] = 0
-                self.Ds[s][all_pairs[:, 0], all_pairs[:, 1]] = full
+                sharding.fill_matrix(self.Ds[s], full, symmetric)
+            # where the call's time went: everything but the similarity() calls is host work (positions -> pairs, the gather,
+            # the matrices); bench.py reports it as host_seconds_outside_kernels
+            self.timing = {"similarity_seconds": t_sim, "pairs": int(K), "pairs_this_rank": int(n_mine)}
             self.get_all_clique_ids()
             if symmetric:
                 for similarity_type in self.Ds:
@@ -230,6 +235,8 @@ class CoverAlgorithm(object):
             if rank == 0:
                 os.makedirs(self.cachedir, exist_ok=True)
                 np.savez(dump, **{k: np.asarray(v) for k, v in self.Ds.items()})
+        if hasattr(self, "timing") and not precomputed:
+            self.timing["all_pairwise_seconds"] = time.time() - tic
         print("Elapsed Time All Pairwise: %.3g" % (time.time() - tic))
 
     def _pair_costs(self, pairs):

@@ -442,6 +442,9 @@ def config3_job(tmpdir, alignments=("qmax", "dmax", "swc")):
     K = ch.n_songs * (ch.n_songs - 1) // 2
     return {"songs": int(ch.n_songs), "pairs": int(K), "alignments": list(alg.alignments),
             "all_pairwise_seconds": round(t1 - t0, 3), "eval_seconds": round(t2 - t1, 3),
+            # all_pairwise minus its similarity() calls: positions -> pairs, the gather, Ds (the calls themselves plan, launch and
+            # wait for the GPU; their host share is the one-call scorer's planning, inside the library)
+            "host_seconds_outside_kernels": round(alg.timing["all_pairwise_seconds"] - alg.timing["similarity_seconds"], 3),
             "pairs_per_s": round(K / (t2 - t0), 1), "pair_scores_per_s": round(len(keys) * K / (t2 - t0), 1),
             "MAP": {k: float(stats[k][3]) for k in keys}, "MR": {k: float(stats[k][0]) for k in keys},
             "Ds_crc32": {k: int(zlib.crc32(np.ascontiguousarray(alg.Ds[k], dtype=np.float32).tobytes())) for k in keys}}
@@ -790,8 +793,8 @@ def extras_scatter_chain(engine, oracle, torch):
 
 def strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use_dist, m, kappa):
     """--strong: the fixed job -- every pair of the corpus (499 500 at the default 1000 songs), chroma_qmax -- sharded over the
-    ranks as CoverAlgorithm.all_pairwise shards it (CoverAlgorithm.py:166-182 is the reference's joblib form): cost-sorted
-    snake deal -> the rank's shard through the one-call scorer (its own batches inside) -> ONE all-gather of the score
+    ranks as CoverAlgorithm.all_pairwise shards it (CoverAlgorithm.py:166-182 is the reference's joblib form): strided
+    positions -> the rank's shard through the one-call scorer (its own batches inside) -> ONE all-gather of the score
     vectors -> Ds (N x N, Ds += Ds.T) on rank 0.  A step is the whole job; per step: barrier + synchronize on both sides,
     max over ranks; value = steps x pairs / that time.  `scores_crc32` lets two runs (1 rank against N) be compared."""
     import zlib
@@ -799,10 +802,10 @@ def strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use
     import torch.distributed as dist
     from acoss_amd import engine, sharding
     K = len(all_pairs)
-    costs = sharding.pair_costs(corpus_h.frame_off, all_pairs, m)
-    shards = [sharding.shard_indices(costs, world, r) for r in range(world)]
-    mine = shards[rank]
-    my_pairs = np.ascontiguousarray(all_pairs[mine])
+    # the shards of CoverAlgorithm.all_pairwise (round 5): rank r takes positions r, r + world, ... of the pair enumeration and
+    # forms its pairs from the positions -- no sort, nothing of size K beyond this bench's own pair list
+    mine = sharding.strided_shard(K, world, rank)
+    my_pairs = np.ascontiguousarray(sharding.pairs_of_positions(corpus_h.n_songs, mine, True).astype(np.int32))
     cdev = dev if backend == "nccl" else torch.device("cpu")
 
     def sync():
@@ -818,9 +821,10 @@ def strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use
         got = engine.serra09_scores(corpus, my_pairs, m=m, kappa=kappa, want=("qmax",))
         t1 = time.perf_counter()
         local = torch.from_numpy(got["qmax"]).to(cdev)
-        full = sharding.gather_scores(local, mine, K, index_of_rank=lambda r: shards[r], force_collective=use_dist)
+        full = sharding.gather_strided(local, K, force_collective=use_dist)
         if rank == 0:
-            Ds = sharding.scatter_to_matrix(all_pairs, full.cpu().numpy(), corpus_h.n_songs, symmetric=True)
+            Ds = sharding.fill_matrix(np.zeros((corpus_h.n_songs, corpus_h.n_songs), dtype=np.float32), full.cpu().numpy(), True)
+            Ds += Ds.T
         sync()
         if rep >= args.warmup:
             elapsed += time.perf_counter() - t0
@@ -836,7 +840,7 @@ def strong_job(args, corpus_h, corpus, all_pairs, dev, rank, world, backend, use
             "dtype": "f32 filter (16-bit keys) + f64 exact refinement (results identical to f64)", "data": "synthetic",
             "config": {"workload": "the whole job: all %d pairs of synthetic %d songs x %d frames x 12-bin HPCP (f64), Serra09 chroma_qmax m=9 "
                                    "kappa=0.095 OTI, sharded over %d rank(s); a step = the job" % (K, args.songs, args.frames, world),
-                       "pairs_per_rank": int(len(mine)), "parallelism": "pair-shard x%d (cost-sorted snake deal), one all-gather, Ds on rank 0" % world,
+                       "pairs_per_rank": int(len(mine)), "parallelism": "pair-shard x%d (every world-th position of the pair enumeration), one all-gather, Ds on rank 0" % world,
                        "collective": ({"backend": dist.get_backend(), "world": world, "ran": ["barrier", "all_gather_into_tensor", "all_reduce(MAX)"]}
                                       if use_dist else None)},
             "rank0_scorer_seconds_per_step": round(shard_s / args.steps, 4),
@@ -897,8 +901,7 @@ def main():
         if use_dist:
             dist.destroy_process_group()
         return
-    costs = sharding.pair_costs(corpus_h.frame_off, all_pairs, m)
-    mine = sharding.shard_indices(costs, world, rank)
+    mine = sharding.strided_shard(len(all_pairs), world, rank)
     P = args.pairs_per_step
     n_steps = args.warmup + args.steps
     # deterministic walk over this rank's shard, wrapping around if the run is longer than the job
