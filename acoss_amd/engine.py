@@ -451,6 +451,20 @@ def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True
     return out, work
 
 
+def radix16_work(batch):
+    """Workspace of radix16_stage() for this batch (uint8 device tensor)."""
+    need = int(_lib.load().acoss_radix16_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))
+    return torch.empty(need, dtype=torch.uint8, device=batch.descs_dev.device)
+
+
+def radix16_stage(what, keys16, band, koff, corpus, batch, kappa, bits, rwork, mutual=True):
+    """Stages of the radix selection that mask_bits_keys16() runs (csrc/radix16_kernels.hip; float64 corpora): what = 1 the
+    column kernel, 2 the row kernel (+ the mask's base bits), 4 exact values of the work items and their cells; combinable."""
+    check(_lib.load().acoss_radix16_stage(int(what), _ptr(keys16), _ptr(band), _ptr(koff), _ptr(corpus.feats), _ptr(corpus.norms), corpus.d,
+                                          _ptr(batch.descs_dev), batch.K, batch.win, batch.max_nx, batch.max_ny, float(kappa),
+                                          1 if mutual else 0, _ptr(bits), _ptr(rwork), rwork.numel(), _stream()), "radix16_stage")
+
+
 def keys16_supported(corpus, batch):
     """float64 or float32 chroma / MFCC-sized features, the reference's window, matrices up to 1024 x 1024."""
     return (corpus.d in (12, 13) and batch.win == 9 and batch.max_nx - batch.win + 1 <= 1024

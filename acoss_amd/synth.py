@@ -60,13 +60,11 @@ def _ar1(rng, shape, scale, rho):
     u = rng.uniform(0.0, scale, size=shape)
     if rho <= 0.0:
         return u
+    from scipy.signal import lfilter
     u -= 0.5 * scale
-    e = np.empty(shape)
-    e[0] = u[0]
     g = np.sqrt(1.0 - rho * rho)
-    for t in range(1, shape[0]):
-        e[t] = rho * e[t - 1] + g * u[t]
-    return e + 0.5 * scale
+    u[0] /= g                                            # so that e_0 = u_0
+    return lfilter([g], [1.0, -rho], u, axis=0) + 0.5 * scale
 
 
 def _base_song(rng, n_frames, nbins, rho=0.0):
