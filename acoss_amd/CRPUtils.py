@@ -4,7 +4,9 @@ hot path: same names, argument meaning and return types (numpy in, numpy out), e
 host wrapper over one batched stage kernel (a batch of one pair here; Serra09.similarity uses
 the batched forms directly).
 
-Not mirrored (off the hot path): get_ssm, get_csm_cosine, sliding_window.
+get_ssm, get_csm_cosine and sliding_window (off the Serra09 path; EarlySNF.py:74-75 and the other plugins import them) are
+thin forms over the same kernel / plain data movement, so that `from CRPUtils import *` against this module finds every name
+the reference's module defines.
 """
 import numpy as np
 
@@ -56,6 +58,39 @@ def get_csm(X, Y, shift=0):
 
 
 get_csm_euclidean = get_csm
+
+
+def get_ssm(X):
+    """CRPUtils.py:48-65: Euclidean self-similarity matrix, zero diagonal (the reference sets it explicitly, :63)."""
+    D = get_csm(X, X)
+    np.fill_diagonal(D, 0)
+    return D
+
+
+def get_csm_cosine(X, Y):
+    """CRPUtils.py:88-107: 1 - cosine of every pair of rows; rows of zero norm count as unit vectors of nothing (their distance
+    to everything is 1, :101-104).  On the normalised clouds 1 - x.y = |x - y|^2 / 2: the Euclidean kernel does the products."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    xn, yn = np.sqrt(np.sum(X ** 2, 1)), np.sqrt(np.sum(Y ** 2, 1))
+    zx, zy = xn == 0, yn == 0
+    xn[zx] = 1
+    yn[zy] = 1
+    C = get_csm(X / xn[:, None], Y / yn[:, None])
+    D = 0.5 * C * C
+    D[zx, :] = 1.0
+    D[:, zy] = 1.0
+    return D
+
+
+def sliding_window(X, win):
+    """CRPUtils.py:8-22: delay embedding of a point cloud, (N - win + 1, d * win) float64 (data movement only)."""
+    X = np.asarray(X)
+    M = X.shape[0] - win + 1
+    Y = np.zeros((max(M, 0), X.shape[1] * win))
+    for i in range(win):
+        Y[:, i * X.shape[1]:(i + 1) * X.shape[1]] = X[i:i + M, :]
+    return Y
 
 
 def sliding_csm(D, win):

@@ -113,6 +113,22 @@ def test_crputils_mirror_functions(golden):
     assert CRPUtils.csm_to_binary(g[p + "S"], kappa).dtype == np.uint8
 
 
+def test_crputils_functions_off_the_serra09_path(golden):
+    """get_ssm (CRPUtils.py:48-65), get_csm_cosine (:88-107), sliding_window (:8-22) against the reference's own outputs."""
+    from acoss_amd import CRPUtils
+    g = golden("crputils_extra")
+    X, Y = g["X"], g["Y"]
+    ssm = CRPUtils.get_ssm(X)
+    assert ssm.shape == (57, 57) and np.all(np.diag(ssm) == 0) and np.max(np.abs(ssm - g["ssm"])) <= 1e-9
+    cos = CRPUtils.get_csm_cosine(X, Y)
+    assert np.max(np.abs(cos - g["cosine"])) <= 1e-9 and np.all(cos[11] == 1.0) and np.all(cos[:, 7] == 1.0)
+    assert np.array_equal(CRPUtils.sliding_window(X, 9), g["window9"]) and np.array_equal(CRPUtils.sliding_window(Y, 1), g["window1"])
+    import acoss_amd.CRPUtils as mod
+    for name in ("sliding_window", "sliding_csm", "get_ssm", "get_csm", "get_csm_euclidean", "get_csm_cosine", "get_oti",
+                 "get_csm_blocked_oti", "csm_to_binary", "csm_to_binary_mutual"):       # every def of the reference's module
+        assert callable(getattr(mod, name))
+
+
 def test_float32_inputs(golden):
     from acoss_amd import CRPUtils
     g = golden("stages")
