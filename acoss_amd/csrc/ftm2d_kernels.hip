@@ -198,10 +198,8 @@ __global__ __launch_bounds__(GM_THREADS) void ftm2d_gram_kernel(const double *__
 {
     __shared__ GemmSmem sm;
     const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
-    gemm_nt_tile_f64(
-        sm, FT_DIM,
-        [&](const int r, const int k) { return (i0 + r < n && k < FT_DIM) ? S[(int64_t)(i0 + r) * FT_DIM + k] : 0.0; },
-        [&](const int r, const int k) { return (j0 + r < n && k < FT_DIM) ? S[(int64_t)(j0 + r) * FT_DIM + k] : 0.0; },
+    gemm_nt_tile_f64_rows(
+        sm, FT_DIM, S + (int64_t)i0 * FT_DIM, FT_DIM, n - i0, S + (int64_t)j0 * FT_DIM, FT_DIM, n - j0,
         [&](const int i, const int j, const double v) {
             if (i0 + i < n && j0 + j < n) {
                 const double d = fmax(fma(-2.0, v, norms[i0 + i] + norms[j0 + j]), 0.0);

@@ -207,22 +207,20 @@ __global__ __launch_bounds__(256) void snf_mean_kernel(const double *const *__re
     out[e] = s / (double)n_src;
 }
 
-// C = X . Y^T per pair (all L x L, row-major): one 128 x 128 tile per block (gemm_f64.h)
+// C = X . Y^T per pair (all L x L, row-major): one 128 x 128 tile per block (gemm_f64.h).  rows_m: only the tiles that hold rows
+// below M -- the last product of the last iteration, whose other rows nobody reads (EarlySNF.py:84-85 takes [0:M, M:]).
 __global__ __launch_bounds__(GM_THREADS) void snf_gemm_nt_kernel(const double *__restrict__ X, const double *__restrict__ Y,
-                                                                 const SnfPair *__restrict__ pairs, double *__restrict__ C)
+                                                                 const SnfPair *__restrict__ pairs, double *__restrict__ C, int rows_m)
 {
     __shared__ GemmSmem sm;
     const SnfPair pr = pairs[blockIdx.z];
     const int L = pr.L;
     const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
-    if (i0 >= L || j0 >= L) return;
+    if (i0 >= (rows_m ? pr.M : L) || j0 >= L) return;
     const double *Xp = X + pr.w_off, *Yp = Y + pr.w_off;
     double *Cp = C + pr.w_off;
-    gemm_nt_tile_f64(
-        sm, L,
-        [&](const int r, const int k) { return (i0 + r < L && k < L) ? Xp[(int64_t)(i0 + r) * L + k] : 0.0; },
-        [&](const int r, const int k) { return (j0 + r < L && k < L) ? Yp[(int64_t)(j0 + r) * L + k] : 0.0; },
-        [&](const int i, const int j, const double v) { if (i0 + i < L && j0 + j < L) Cp[(int64_t)(i0 + i) * L + j0 + j] = v; });
+    gemm_nt_tile_f64_rows(sm, L, Xp + (int64_t)i0 * L, L, L - i0, Yp + (int64_t)j0 * L, L, L - j0,
+                          [&](const int i, const int j, const double v) { if (i0 + i < L && j0 + j < L) Cp[(int64_t)(i0 + i) * L + j0 + j] = v; });
 }
 
 // -(mean_f P_f)[0:M, M:] into the pair's cross-recurrence layout (EarlySNF.py:84-85)
@@ -340,9 +338,12 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                 hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n, tot, Xm);
                 src = Xm;
             }
-            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], src, d_tab, Am);       // A = S . P^T   (:251)
+            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], src, d_tab, Am, 0);    // A = S . P^T   (:251)
             double *dst = (it == 0) ? Pn[i] : Pm[i];
-            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], Am, d_tab, dst);       // S . A^T       (:252)
+            // the very last product: only rows 0 .. M - 1 are ever read (by snf_cross_kernel) -- unless the caller wants the whole
+            // fused matrix (debug_fused), or further features of this iteration read it (they read the features before them)
+            const int rows_m = (it == niters - 1 && i == n_feat - 1 && debug_fused == nullptr) ? 1 : 0;
+            hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], Am, d_tab, dst, rows_m);       // S . A^T       (:252)
             hipLaunchKernelGGL(snf_rowsum_kernel, g_row, dim3(256), 0, st, dst, d_tab, rowsum);
             hipLaunchKernelGGL(snf_reg_kernel, g_el, dim3(256), 0, st, dst, d_tab, rowsum, dst);          // :254-262
             rc = launch_check("snf diffusion kernels");
