@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG, "libacoss_mi355x.so")
+# (ACOSS_LIB_PATH: another build of the library -- tools/build_variant.py -- for A/B runs of the tests and tools)
+LIB_PATH = os.environ.get("ACOSS_LIB_PATH") or os.path.join(PKG, "libacoss_mi355x.so")
 
 PAIR_DESC = np.dtype([
     ("x_row0", "<i8"), ("y_row0", "<i8"), ("csm_off", "<i8"), ("crp_off", "<i8"),

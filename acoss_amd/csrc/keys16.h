@@ -276,7 +276,11 @@ __device__ inline uint64_t k16_bin_keys(const u16x2 (&h)[8], unsigned binlo, uns
     for (int v = 0; v < 8; v++) mo = __builtin_elementwise_min(mo, h[v] - bl_pk);
     const unsigned off = min((unsigned)mo.x, (unsigned)mo.y);
     ch = binlo + off;
+#ifdef K16_REGRESSION_D26CA8D          // (tools/build_variant.py: the line as it stood before d26ca8d, for tests/test_gpu_keys16.py's regression test)
+    return __ballot(off <= binw);
+#else
     return __ballot(off <= min(binw, 0xFFFFu - binlo));
+#endif
 }
 
 // k-th smallest of the wave's 16-bit keys: lane l holds positions 16 l .. 16 l + 15 as eight packed pairs (position

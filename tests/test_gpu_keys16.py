@@ -301,3 +301,66 @@ def test_float32_corpus_scores_through_the_engine(eng, orc):
         q = orc.qmax(Bf, D, M, N) / (M + N)
         dm = orc.dmax(Bf, D, M, N) / (M + N)
         assert got["qmax"][t] == q and got["dmax"][t] == dm, (t, i, j)
+
+
+def _wrapped_bin_planes():
+    """Two 1024 x 1024 key planes (no padding) for the regression test below.  Every row and column of the base plane is a
+    permutation of 20000 + 4 t (gaps of four keys: nothing within reach of anything).  Plane A, rows 0 and 1; plane B (its
+    transpose), columns 0 and 1: the first has its third-largest key at 65522; the second holds 65522, then 65524 and 65526 in
+    ONE lane (neighbouring positions 200, 201), 65530, 65534, and a key 0 -- with k = 1022 its k-th smallest key is 65526, and the
+    histogram window predicted from 65522 puts it into the bin [65522, 65537], which reaches past the top of the key range; the
+    key 0 sits 14 below that bin modulo 2^16."""
+    n = 1024
+    i, j = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    base = (20000 + 4 * ((i * 5 + j * 7) % n)).astype(np.uint16)
+    A = base.copy()
+    A[0, 500], A[0, 550], A[0, 600] = 65530, 65526, 65522
+    A[1, 100], A[1, 200], A[1, 201], A[1, 300], A[1, 350], A[1, 400] = 65522, 65524, 65526, 65530, 65534, 0
+    return A, np.ascontiguousarray(A.T)
+
+
+@pytest.mark.parametrize("radix", [False, True])
+def test_histogram_bin_that_reaches_past_the_top_of_the_key_range(eng, radix):
+    """Regression test for commit d26ca8d (csrc/keys16.h, k16_bin_keys): offsets from the bin's first key are taken modulo 2^16,
+    so a bin that reaches past key 0xFFFF took keys far BELOW it for its own; with two of the bin's real keys in one lane the
+    lane count still matched and the threshold came out as 65530 instead of 65526 (one cell too many selected).  Checked by building the library with
+    -DK16_REGRESSION_D26CA8D (the old line) and running this test against it (ACOSS_LIB_PATH): the wave-per-row form fails there
+    (profiles/r05_regression_d26ca8d.txt).  The key planes are synthetic (decided by the keys alone: no cell within reach of a
+    threshold), k = 1022 of 1024; also through the radix selection, which has no such bins."""
+    import os
+    import torch
+    rng = np.random.default_rng(9)
+    feats = rng.random((2 * 1032, 12)) + 0.1
+    off = np.array([0, 1032, 2064], dtype=np.int64)
+    corpus = eng.DeviceCorpus(feats, off, gchroma=np.ones((2, 12)))
+    batch = eng.PairBatch(corpus.frame_off, np.array([(0, 1), (1, 0)], dtype=np.int32), 9, corpus.device, pitch_align=32)
+    A, B = _wrapped_bin_planes()
+    plane = np.zeros(batch.total_crp + 64, dtype=np.uint16)
+    for p, P in enumerate((A, B)):
+        d = batch.descs[p]
+        assert int(d["crp_pitch"]) == 1024
+        plane[int(d["crp_off"]):int(d["crp_off"]) + 1024 * 1024] = P.reshape(-1)
+    k16 = torch.from_numpy(plane.view(np.int16)).to(corpus.device)
+    xp32 = eng.pack_x32(corpus, batch)
+    band = torch.tensor([0.0, 1e-9] * 2, dtype=torch.float32, device=corpus.device)
+    koff = torch.tensor([0x3C000000, 0x3C000000], dtype=torch.int32, device=corpus.device)
+    old = os.environ.get("ACOSS_RADIX16")
+    os.environ["ACOSS_RADIX16"] = "1" if radix else "0"
+    try:
+        rows_only, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 1022, mutual=False)
+        rows_only = rows_only.clone()
+        both, _ = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 1022, mutual=True)
+    finally:
+        if old is None:
+            os.environ.pop("ACOSS_RADIX16", None)
+        else:
+            os.environ["ACOSS_RADIX16"] = old
+
+    def kth(P, axis):
+        return np.sort(P.astype(np.int64), axis=axis).take(1021, axis=axis)
+    want_rows = (A.astype(np.int64) <= kth(A, 1)[:, None]).astype(np.uint8)
+    assert kth(A, 1)[0] == 65522 and kth(A, 1)[1] == 65526 and want_rows[1].sum() == 1022 and want_rows[1, 300] == 0
+    assert np.array_equal(eng.unpack_mask_bits(rows_only, batch, 0), want_rows)
+    want_b = ((B.astype(np.int64) <= kth(B, 1)[:, None]) & (B.astype(np.int64) <= kth(B, 0)[None, :])).astype(np.uint8)
+    assert kth(B, 0)[1] == 65526
+    assert np.array_equal(eng.unpack_mask_bits(both, batch, 1), want_b)
