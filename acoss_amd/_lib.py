@@ -81,6 +81,8 @@ SIGNATURES = {
     "acoss_keys16_koff_f32_batch": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
     "acoss_mask_bits_keys16_f32_batch": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),
     "acoss_mask_bits_keys16_stats": (_i, [_vp, _i, _i, _i, _i, _vp]),
+    "acoss_mask_bits_keys16_unresolved": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _vp]),
+    "acoss_radix16_enabled": (_i, []),
     "acoss_radix16_work_bytes": (_sz, [_i, _i, _i, _i]),
     "acoss_radix16_layout": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "acoss_radix16_stage": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _dbl, _i, _vp, _vp, _sz, _vp]),

@@ -874,7 +874,8 @@ __global__ __launch_bounds__(256, 4) void dp_bits_d16_kernel(const uint64_t *__r
 // the (i-3, j-1) predecessor is carried -- c4(i) = D[i-3][j-1] + S[i-2][j] + S[i-1][j] = c2(i-1) + S[i-1][j], where c2(i-1) is
 // the previous row's (i-2, j-1) term -- so neither the row i-3 nor the mask values of row i-2 are kept.  Scores identical by construction
 // (integers).
-__global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__restrict__ bits,
+template <int R>
+__global__ __launch_bounds__(256, R == 8 ? 4 : (R == 12 ? 3 : 2)) void dp_bits_qd16_kernel(const uint64_t *__restrict__ bits,
                                                                const acoss_pair_desc *__restrict__ descs, int K, int win,
                                                                int max_m, int boundary, float *__restrict__ qscores,
                                                                float *__restrict__ dscores)
@@ -902,26 +903,42 @@ __global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__
         return;
     }
     const bool with_d = M >= 4 && N >= 4;        // SequenceAlignment.c:151-153: dmax of a smaller matrix is 0 (wave-uniform)
-    const unsigned short *rowp = reinterpret_cast<const unsigned short *>(bits + (int64_t)p * max_m * 16) + lane;
+    // R registers of two 16-bit cells per lane: 2 R columns, their mask bits 2 R bits from bit 2 R lane of the row.  R = 8: rows of
+    // 16 words (<= 1024 columns); R = 12 / 16: rows of 32 words, <= 1536 / 2048 columns (E = 2 D < 2 min(M, N) + 2 <= 4098 either way)
+    constexpr int ROWB = R == 8 ? 128 : 256;                 // bytes per row of the mask
+    const unsigned char *rowb = reinterpret_cast<const unsigned char *>(bits) + (int64_t)p * max_m * ROWB + lane * (R / 4);
+    auto load_row = [&](const int i) -> unsigned {
+        const unsigned char *src = rowb + (int64_t)i * ROWB;
+        if (R == 8) return (unsigned)*reinterpret_cast<const unsigned short *>(src);
+        if (R == 16) return *reinterpret_cast<const unsigned *>(src);
+        unsigned v;                                           // R == 12: three bytes from byte 3 lane (the fourth is the next lane's or the row's unused tail)
+        __builtin_memcpy(&v, src, 4);
+        return v & 0xFFFFFFu;
+    };
     auto pk = [](unsigned v) { return __builtin_bit_cast(dp_u16x2, v); };
     auto un = [](dp_u16x2 v) { return __builtin_bit_cast(unsigned, v); };
     const dp_u16x2 one = (dp_u16x2){1, 1};
     const bool l0 = lane == 0;
     // qmax state: row i-1; rows i-1 and i-2 shifted right by one cell
-    unsigned q1[8], q1s[8], q2s[8], qbest = 0u;
+    unsigned q1[R], q1s[R], q2s[R], qbest = 0u;
     // dmax state: row i-1; rows i-1 and i-2 shifted right by one cell; the previous row's (i-2, j-1) term; mask values of row i-1
-    unsigned d1[8], d1s[8], d2s[8], c2p[8], a1[8], dbest = 0u;
+    unsigned d1[R], d1s[R], d2s[R], c2p[R], a1[R], dbest = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; k++) q1[k] = q1s[k] = q2s[k] = d1[k] = d1s[k] = d2s[k] = c2p[k] = a1[k] = 0u;
-    auto unpack = [](const uint4 a, const uint4 b, unsigned (&o)[8]) {
-        o[0] = a.x; o[1] = a.y; o[2] = a.z; o[3] = a.w; o[4] = b.x; o[5] = b.y; o[6] = b.z; o[7] = b.w;
+    for (int k = 0; k < R; k++) q1[k] = q1s[k] = q2s[k] = d1[k] = d1s[k] = d2s[k] = c2p[k] = a1[k] = 0u;
+    // a row's mask bits -> per register the two cells' values (3 / 2 per set bit), a byte of bits at a time
+    auto unpack = [](const uint4 *lut, const unsigned m, unsigned (&o)[R]) {
+#pragma unroll
+        for (int b = 0; b < R / 4; b++) {
+            const uint4 a = lut[(m >> (8 * b)) & 0xFFu];
+            o[4 * b] = a.x; o[4 * b + 1] = a.y; o[4 * b + 2] = a.z; o[4 * b + 3] = a.w;
+        }
     };
     // one row of qmax (dp_bits_q16_kernel's)
-    auto q_row = [&](const unsigned (&m3)[8]) {
-        const unsigned halo = (unsigned)lane_shr1((int)q1[7], 0);
-        unsigned nd[8];
+    auto q_row = [&](const unsigned (&m3)[R]) {
+        const unsigned halo = (unsigned)lane_shr1((int)q1[R - 1], 0);
+        unsigned nd[R];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < R; k++) {
             const unsigned left2 = k >= 1 ? q1[k - 1] : halo;
             const dp_u16x2 m = __builtin_elementwise_max(__builtin_elementwise_max(pk(q1s[k]), pk(q2s[k])), pk(left2));
             unsigned v = un(__builtin_elementwise_sub_sat(m + pk(m3[k]), one));
@@ -930,21 +947,21 @@ __global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__
             nd[k] = v;
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) q2s[k] = q1s[k];
+        for (int k = 0; k < R; k++) q2s[k] = q1s[k];
 #pragma unroll
-        for (int k = 7; k >= 1; k--) q1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
-        q1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+        for (int k = R - 1; k >= 1; k--) q1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        q1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[R - 1], 0), 16);
 #pragma unroll
-        for (int k = 0; k < 8; k++) q1[k] = nd[k];
+        for (int k = 0; k < R; k++) q1[k] = nd[k];
     };
     // one row of dmax (dp_bits_d16_kernel's, with the carried (i-3, j-1) term)
-    auto d_row = [&](const unsigned (&m3)[8], const unsigned (&a0)[8]) {
-        const unsigned a0_prev = (unsigned)lane_shr1((int)a0[7], 0);
-        const unsigned d1_prev = (unsigned)lane_shr1((int)d1[7], 0);
-        const unsigned d1s_prev = (unsigned)lane_shr1((int)d1s[7], 0);
-        unsigned nd[8];
+    auto d_row = [&](const unsigned (&m3)[R], const unsigned (&a0)[R]) {
+        const unsigned a0_prev = (unsigned)lane_shr1((int)a0[R - 1], 0);
+        const unsigned d1_prev = (unsigned)lane_shr1((int)d1[R - 1], 0);
+        const unsigned d1s_prev = (unsigned)lane_shr1((int)d1s[R - 1], 0);
+        unsigned nd[R];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
+        for (int k = 0; k < R; k++) {
             const unsigned a0m1 = k >= 1 ? a0[k - 1] : a0_prev;                    // S[i][j-2] (x 2)
             const dp_u16x2 sl1 = pk(__builtin_amdgcn_alignbit(a0[k], a0m1, 16));   // S[i][j-1]
             const dp_u16x2 su1 = pk(a1[k]);                                          // S[i-1][j]
@@ -966,28 +983,28 @@ __global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__
             c2p[k] = un(c2);
         }
 #pragma unroll
-        for (int k = 0; k < 8; k++) { d2s[k] = d1s[k]; a1[k] = a0[k]; }
+        for (int k = 0; k < R; k++) { d2s[k] = d1s[k]; a1[k] = a0[k]; }
 #pragma unroll
-        for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
-        d1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[7], 0), 16);
+        for (int k = R - 1; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(nd[k], nd[k - 1], 16);
+        d1s[0] = __builtin_amdgcn_alignbit(nd[0], (unsigned)lane_shr1((int)nd[R - 1], 0), 16);
 #pragma unroll
-        for (int k = 0; k < 8; k++) d1[k] = nd[k];
+        for (int k = 0; k < R; k++) d1[k] = nd[k];
     };
     // rows 1 and 2: dmax only takes their mask values (c2p = 0 + S[1][j]: the carried term of row 3; with the boundary row 2 of D
     // holds its mask values in columns >= 2); qmax computes row 2
     {
-        const unsigned r1 = rowp[(int64_t)1 * 64], r2 = rowp[(int64_t)2 * 64];
-        unsigned m3[8];
-        unpack(lut2[r1 & 0xFFu], lut2[(r1 >> 8) & 0xFFu], c2p);
-        unpack(lut2[r2 & 0xFFu], lut2[(r2 >> 8) & 0xFFu], a1);
-        unpack(lut3[r2 & 0xFFu], lut3[(r2 >> 8) & 0xFFu], m3);
+        const unsigned r1 = load_row(1), r2 = load_row(2);
+        unsigned m3[R];
+        unpack(lut2, r1, c2p);
+        unpack(lut2, r2, a1);
+        unpack(lut3, r2, m3);
         if (boundary) {
 #pragma unroll
-            for (int k = 0; k < 8; k++) d1[k] = a1[k];
+            for (int k = 0; k < R; k++) d1[k] = a1[k];
             if (l0) d1[0] = 0u;
 #pragma unroll
-            for (int k = 7; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(d1[k], d1[k - 1], 16);
-            d1s[0] = __builtin_amdgcn_alignbit(d1[0], (unsigned)lane_shr1((int)d1[7], 0), 16);
+            for (int k = R - 1; k >= 1; k--) d1s[k] = __builtin_amdgcn_alignbit(d1[k], d1[k - 1], 16);
+            d1s[0] = __builtin_amdgcn_alignbit(d1[0], (unsigned)lane_shr1((int)d1[R - 1], 0), 16);
         }
         q_row(m3);
     }
@@ -995,15 +1012,15 @@ __global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__
     if (with_d) {
         unsigned ring[PF];
 #pragma unroll
-        for (int u = 0; u < PF; u++) ring[u] = rowp[(int64_t)min(i + u, M - 1) * 64];
+        for (int u = 0; u < PF; u++) ring[u] = load_row(min(i + u, M - 1));
         for (; i + PF <= M; i += PF) {
 #pragma unroll
             for (int u = 0; u < PF; u++) {
                 const unsigned m0 = ring[u];
-                ring[u] = rowp[(int64_t)min(i + u + PF, M - 1) * 64];
-                unsigned m3[8], a0[8];
-                unpack(lut3[m0 & 0xFFu], lut3[(m0 >> 8) & 0xFFu], m3);
-                unpack(lut2[m0 & 0xFFu], lut2[(m0 >> 8) & 0xFFu], a0);
+                ring[u] = load_row(min(i + u + PF, M - 1));
+                unsigned m3[R], a0[R];
+                unpack(lut3, m0, m3);
+                unpack(lut2, m0, a0);
                 q_row(m3);
                 d_row(m3, a0);
             }
@@ -1011,10 +1028,10 @@ __global__ __launch_bounds__(256, 4) void dp_bits_qd16_kernel(const uint64_t *__
     }
 #pragma unroll 1
     for (; i < M; i++) {
-        const unsigned m0 = rowp[(int64_t)i * 64];
-        unsigned m3[8], a0[8];
-        unpack(lut3[m0 & 0xFFu], lut3[(m0 >> 8) & 0xFFu], m3);
-        unpack(lut2[m0 & 0xFFu], lut2[(m0 >> 8) & 0xFFu], a0);
+        const unsigned m0 = load_row(i);
+        unsigned m3[R], a0[R];
+        unpack(lut3, m0, m3);
+        unpack(lut2, m0, a0);
         q_row(m3);
         if (with_d) d_row(m3, a0);
     }
@@ -1268,10 +1285,16 @@ int acoss_align_bits_qd_batch(const uint64_t *bits, const acoss_pair_desc *descs
     // one-sweep kernel (2.02 ms: 230 registers, two waves per SIMD).  ACOSS_DP_ONE_SWEEP=1 keeps the old form.
     static const bool one_sweep = []() { const char *e = getenv("ACOSS_DP_ONE_SWEEP"); return e && e[0] == '1'; }();
     static const bool q16 = []() { const char *e = getenv("ACOSS_DP_Q16"); return !(e && e[0] == '0'); }();
-    if (DP_QD16_DEFAULT && !one_sweep && q16 && ap.gamma_onset == 0.5f && mask_bits_words(max_m, max_n) == 16) {
-        // round 4: both recurrences in 16-bit integers in one sweep (dp_bits_qd16_kernel)
-        hipLaunchKernelGGL(dp_bits_qd16_kernel, dim3(ceil_div(K, 4)), dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m, boundary,
-                           qmax_scores, dmax_scores);
+    if (DP_QD16_DEFAULT && !one_sweep && q16 && ap.gamma_onset == 0.5f) {
+        // round 4: both recurrences in 16-bit integers in one sweep (dp_bits_qd16_kernel); round 5: also on the 32-word rows of
+        // matrices beyond 1024 columns, 24 or 32 columns per lane
+        const dim3 grid(ceil_div(K, 4));
+        if (mask_bits_words(max_m, max_n) == 16)
+            hipLaunchKernelGGL(dp_bits_qd16_kernel<8>, grid, dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m, boundary, qmax_scores, dmax_scores);
+        else if (max_n <= 1536)
+            hipLaunchKernelGGL(dp_bits_qd16_kernel<12>, grid, dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m, boundary, qmax_scores, dmax_scores);
+        else
+            hipLaunchKernelGGL(dp_bits_qd16_kernel<16>, grid, dim3(256), 0, (hipStream_t)stream, bits, descs, K, win, max_m, boundary, qmax_scores, dmax_scores);
         return launch_check("dp_bits_qd16_kernel");
     }
     if (!one_sweep) {

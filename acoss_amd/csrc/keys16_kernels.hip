@@ -538,11 +538,22 @@ static int mask_bits_keys16_impl(const uint16_t *keys16, const float *band, cons
     }
     if ((d != 12 && d != 13) || win != 9) { set_error("mask_bits_keys16_batch: supports d in {12, 13} and win == 9"); return ACOSS_ENOTSUP; }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    if (max_m > 1024 || max_n > 1024) { set_error("mask_bits_keys16_batch: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
+    if (max_m > 2048 || max_n > 2048) { set_error("mask_bits_keys16_batch: matrices up to 2048 x 2048"); return ACOSS_ENOTSUP; }
+    const bool lng = max_m > 1024 || max_n > 1024;
+    if (lng && !((mutual == 0 || mutual == 1) && radix16_enabled())) {
+        set_error("mask_bits_keys16_batch: matrices beyond 1024 x 1024 need the radix selection (ACOSS_RADIX16)");
+        return ACOSS_ENOTSUP;
+    }
     if (work_bytes < thresh_work_bytes(K, max_m, max_n, true)) { set_error("mask_bits_keys16_batch: workspace too small"); return ACOSS_EINVAL; }
     if (K == 0) return ACOSS_OK;
     hipStream_t st = (hipStream_t)stream;
     ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    if (lng) {
+        // ---- the long form (a side of 1025 .. 2048): the radix selection alone.  Pairs it cannot express stay UNRESOLVED (their
+        // mask rows are undefined): acoss_mask_bits_keys16_unresolved() lists them, the caller redoes them on the float64 path
+        // (acoss_crp_planar_batch_f64 + acoss_mask_bits_planar_batch; acoss_serra09_scores does)
+        return r16_run<FT>(7, keys16, band, koff, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, w.radix, st);
+    }
     w.band = band;
     ACOSS_HIP(hipMemsetAsync(w.side_counter, 0, 256, st));
     double kv;
@@ -642,12 +653,43 @@ extern "C" int acoss_mask_bits_keys16_stats(void *work, int K, int max_nx, int m
     if (!work || !out || K <= 0) { set_error("mask_bits_keys16_stats: bad argument"); return ACOSS_EINVAL; }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
     const ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
-    if (w.radix == nullptr) { set_error("mask_bits_keys16_stats: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
+    if (w.radix == nullptr) { set_error("mask_bits_keys16_stats: matrices up to 2048 x 2048"); return ACOSS_ENOTSUP; }
     const R16Work rw = r16_work_layout(w.radix, K, max_m, max_n);
     ACOSS_HIP(hipDeviceSynchronize());
     ACOSS_HIP(hipMemcpy(out, rw.counters, 20 * sizeof(int), hipMemcpyDeviceToHost));
     return ACOSS_OK;
 }
+
+// The pairs the last acoss_mask_bits_keys16(_f32)_batch call on this workspace left UNRESOLVED (waits for `stream`).  Matrices up
+// to 1024 x 1024: always none (the wave-per-row kernels redo what the radix selection hands back).  Beyond (up to 2048 x 2048):
+// the pairs whose rows or columns hold more cells inside the reach of their k-th smallest key than a work item holds (exact
+// ties, thresholds below the key range) -- their rows of `bits` are undefined and the caller takes them through the float64 path.
+// list: room for `cap` pair indices (K is always enough); *n: how many there are (may exceed cap: then only cap are listed).
+extern "C" int acoss_mask_bits_keys16_unresolved(void *work, int K, int max_nx, int max_ny, int win, int32_t *list, int cap, int *n,
+                                                 void *stream)
+{
+    if (!work || !n || K < 0 || cap < 0 || (cap > 0 && !list)) { set_error("mask_bits_keys16_unresolved: bad argument"); return ACOSS_EINVAL; }
+    *n = 0;
+    const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
+    if (K == 0 || (max_m <= 1024 && max_n <= 1024)) return ACOSS_OK;
+    const ThreshWork w = thresh_work_layout(work, K, max_m, max_n, true);
+    if (w.radix == nullptr) { set_error("mask_bits_keys16_unresolved: matrices up to 2048 x 2048"); return ACOSS_ENOTSUP; }
+    const R16Work rw = r16_work_layout(w.radix, K, max_m, max_n);
+    hipStream_t st = (hipStream_t)stream;
+    int count = 0;
+    ACOSS_HIP(hipMemcpyAsync(&count, rw.counters + 2, sizeof(int), hipMemcpyDeviceToHost, st));
+    ACOSS_HIP(hipStreamSynchronize(st));
+    count = count < 0 ? 0 : (count > K ? K : count);
+    *n = count;
+    const int take = count < cap ? count : cap;
+    if (take > 0) {
+        ACOSS_HIP(hipMemcpyAsync(list, rw.pair_list, sizeof(int) * (size_t)take, hipMemcpyDeviceToHost, st));
+        ACOSS_HIP(hipStreamSynchronize(st));
+    }
+    return ACOSS_OK;
+}
+
+extern "C" int acoss_radix16_enabled(void) { return radix16_enabled() ? 1 : 0; }
 
 // koff[pair] for acoss_crp_keys16_batch / acoss_mask_bits_keys16_f32_batch on a float32 corpus (k16_koff_pair_kernel: the key
 // range hung on norms centred per pair).  xp / f32 / n32 / descs: exactly what acoss_crp_keys16_batch will be given.

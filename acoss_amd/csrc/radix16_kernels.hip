@@ -65,9 +65,11 @@ struct R16Lds {
     unsigned dec[R16_LINES], rcnt[R16_LINES];
     int ditem[R16_LINES], nr[R16_LINES];
     unsigned sweep3, item_n;
-    uint4 tcol[128];                           // row kernel: the pair's column bounds
+    uint4 tcol[256];                           // row kernel: the pair's column bounds (2048 columns in the long form)
 };
-constexpr int R16_SLOTS = 8;                   // hits a thread can hold (x | position << 9 | line << 19 each).  A thread with more
+constexpr int R16_LINE_SHIFT = 20;             // a hit: x (9 bits) | position << 9 (11 bits) | line << 20
+constexpr unsigned R16_POS_MASK = 0x7FFu;
+constexpr int R16_SLOTS = 8;                   // hits a thread can hold.  A thread with more
                                                // (temporally smooth features: runs of neighbouring cells inside one window) still
                                                // COUNTS them all; the block then finds the items' cells by a third sweep
 
@@ -215,9 +217,9 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
         const unsigned *hcnt = sm.S;
         auto take = [&](const unsigned rec) {
             const int x = (int)(rec & 0x1FFu);
-            if (((int)(rec >> 19) == line) & (x >= lo) & (x <= hi)) {
+            if (((int)(rec >> R16_LINE_SHIFT) == line) & (x >= lo) & (x <= hi)) {
                 const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
-                if (slot < (unsigned)R16_CAP) it->pos[slot] = (uint16_t)((rec >> 9) & 0x3FFu);
+                if (slot < (unsigned)R16_CAP) it->pos[slot] = (uint16_t)((rec >> 9) & R16_POS_MASK);
             }
         };
 #pragma unroll
@@ -236,11 +238,11 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
 //        j = (l >> 4) + 4 (v & 3) -- a wave instruction reads 64 contiguous bytes of each of sixteen rows, and the 32 lanes of an LDS
 //        lane group belong to sixteen different rows.  With both bounds known the row kernel writes the mutual mask's base bits
 //        key < min(t1_row, t1_col) from its registers.
-template <int DIR>
-__global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
+template <int DIR, int NQ>
+__global__ __launch_bounds__(R16_THREADS, NQ == 32 ? 8 : (NQ == 48 ? 6 : 4)) void r16_select_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
                                                                     int win, double kv, int k_mode, R16Work w, int ldm, int ldn, int tiles,
                                                                     const float *__restrict__ band, const uint32_t *__restrict__ koff_of,
-                                                                    int mutual, uint64_t *__restrict__ bits, int item0, int dbg)
+                                                                    int mutual, uint64_t *__restrict__ bits, int wpr, int item0, int dbg)
 {
     __shared__ __attribute__((aligned(16))) R16Lds sm;
     const int lb = xcd_remap(blockIdx.x, gridDim.x);
@@ -265,7 +267,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
     }
     typedef unsigned int u32x4v __attribute__((ext_vector_type(4)));
     // ---- the tile's keys: 32 dwords per thread, every load in flight before the first is used
-    unsigned wv[32];
+    unsigned wv[NQ];
     const int pi = t & (R16_WORDS - 1), rs = t / R16_WORDS;   // columns (rs: 0 .. 31)
     const int wave = t >> 6;
     const int rr = 16 * (wave >> 2) + (lane & 15), jj = (lane >> 4) + 4 * (wave & 3);      // rows
@@ -277,13 +279,13 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             // (column pairs past the pitch repeat the last pair: their lines do not exist)
             const uint16_t *base = keys + ds.crp_off + min(c0, max(ds.crp_pitch - 2, 0)) + (int64_t)rs * ds.crp_pitch;
 #pragma unroll
-            for (int q = 0; q < 32; q++)
+            for (int q = 0; q < NQ; q++)
                 wv[q] = rs + 32 * q < M ? R16_COL_LOAD(reinterpret_cast<const unsigned *>(base + q * rstep)) : 0xFFFFFFFFu;
         } else {
             const bool ha = c0 < ds.crp_pitch, hb = c0 + 1 < ds.crp_pitch;
             const uint16_t *base = keys + ds.crp_off + (ha ? c0 : 0) + (int64_t)rs * ds.crp_pitch;
 #pragma unroll
-            for (int q = 0; q < 32; q++) {
+            for (int q = 0; q < NQ; q++) {
                 const uint16_t *s = base + q * rstep;
                 wv[q] = rs + 32 * q < M ? ((ha ? (unsigned)s[0] : 0xFFFFu) | ((hb ? (unsigned)s[1] : 0xFFFFu) << 16)) : 0xFFFFFFFFu;
             }
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         const bool fast = ((ds.crp_pitch & 7) == 0) && ((ds.crp_off & 7) == 0);
         const int i = l0 + rr;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < NQ / 4; q++) {
             const int c0 = 8 * (jj + 16 * q);
             u32x4v v = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (i < M && c0 < N) {
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
 #pragma unroll
             for (int d = 0; d < 4; d++) wv[4 * q + d] = v[d];
         }
-        if (t < 128) {
+        if (t < 4 * NQ) {
             u32x4v tc = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
             if (mutual && 8 * t < N) tc = *reinterpret_cast<const u32x4v *>(w.t1_col + (int64_t)p * ldn + 8 * t);
             sm.tcol[t] = make_uint4(tc[0], tc[1], tc[2], tc[3]);
@@ -325,12 +327,12 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
     if (dbg == 1) {                                         // development: the loads alone
         unsigned a = 0;
 #pragma unroll
-        for (int q = 0; q < 32; q++) a ^= wv[q];
+        for (int q = 0; q < NQ; q++) a ^= wv[q];
         if (a == 0x12345678u) t1_out[0] = 1;
         return;
     }
     // register dwords that can hold keys of the matrix (block-uniform; songs shorter than 1024 frames: the sweeps stop there)
-    const int q_end = DIR ? min(32, (M + 31) >> 5) : min(32, 4 * ((N + 127) >> 7));
+    const int q_end = DIR ? min(NQ, (M + 31) >> 5) : min(NQ, 4 * ((N + 127) >> 7));
     if (!trivial) {
         {
             uint4 *hz = reinterpret_cast<uint4 *>(sm.hist);
@@ -353,12 +355,12 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                 r16_lds_add(lanebase + ((x >> R16_BINSHIFT) & R16_BINMASK), vlo);
                 r16_lds_add(lanebase + ((x >> (16 + R16_BINSHIFT)) & R16_BINMASK), vhi);
             };
-            if (q_end == 32) {                              // (block-uniform: the full-size form has no tests inside)
+            if (q_end == NQ) {                              // (block-uniform: the full-size form has no tests inside)
 #pragma unroll
-                for (int q = 0; q < 32; q++) bin(q);
+                for (int q = 0; q < NQ; q++) bin(q);
             } else {
 #pragma unroll
-                for (int q = 0; q < 32; q++)
+                for (int q = 0; q < NQ; q++)
                     if (q < q_end) bin(q);
             }
         }
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const int la = DIR ? 2 * pi : rr, lb2 = DIR ? 2 * pi + 1 : rr;
             const unsigned b0 = (unsigned)(256 * sm.lineB[la] - 1) & 0xFFFFu, b1 = (unsigned)(256 * sm.lineB[lb2] - 1) & 0xFFFFu;
             const u16x2 bsh = k16_from_u32(b0 | (b1 << 16));
-            // A hit is only KEPT inside the sweep -- x | position << 9 | line << 19 into the thread's own column of the slot table
+            // A hit is only KEPT inside the sweep -- x | position << 9 | line << 20 into the thread's own column of the slot table
             // that takes the place of the histogram -- and counted afterwards, all lanes their q-th hit together: a block of the
             // sweep runs for the whole wave when one lane hits (0.78 times per dword), the counting once per hit.
             // (lines past the end of the matrix -- padding, or whatever lies behind a row -- take no part)
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             unsigned hc = 0;
             const unsigned slotbase = r16_lds_off(sm.hist) + 4u * (unsigned)t;
             auto count = [&](const unsigned rec) {
-                const unsigned x = rec & 0x1FFu, line = rec >> 19;
+                const unsigned x = rec & 0x1FFu, line = rec >> R16_LINE_SHIFT;
                 if (x - 1u < 256u) atomicAdd(&sm.sub[((x - 1u) >> 4) * R16_LINES + line], 1u);
                 atomicAdd(&sm.fine[x * (R16_LINES / 4) + (line >> 2)], 1u << (8 * (line & 3)));
             };
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                 }
                 hc++;
             };
-            const unsigned rec_a = (unsigned)la << 19, rec_b = ((unsigned)lb2 << 19) | (DIR ? 0u : 1u << 9);
+            const unsigned rec_a = (unsigned)la << R16_LINE_SHIFT, rec_b = ((unsigned)lb2 << R16_LINE_SHIFT) | (DIR ? 0u : 1u << 9);
             auto test = [&](const int q) {
                 const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
                 const unsigned xl = x & 0xFFFFu, xh = x >> 16;
@@ -410,12 +412,12 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                 if (xl < lim_a) hit((xl | (pos << 9)) + rec_a);
                 if (xh < lim_b) hit((xh | (pos << 9)) + rec_b);
             };
-            if (q_end == 32) {
+            if (q_end == NQ) {
 #pragma unroll
-                for (int q = 0; q < 32; q++) test(q);
+                for (int q = 0; q < NQ; q++) test(q);
             } else {
 #pragma unroll
-                for (int q = 0; q < 32; q++)
+                for (int q = 0; q < NQ; q++)
                     if (q < q_end) test(q);
             }
             const unsigned kept = min(hc, (unsigned)R16_SLOTS);
@@ -449,7 +451,7 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
             const unsigned wid_a = ha ? ((da >> 10) & 0x1FFu) - lo_a + 1u : 0u, wid_b = hb ? ((db >> 10) & 0x1FFu) - lo_b + 1u : 0u;
             R16Item *ia = w.items + (ha ? sm.ditem[la] : 0), *ib = w.items + (hb ? sm.ditem[lb2] : 0);
 #pragma unroll
-            for (int q = 0; q < 32; q++) {
+            for (int q = 0; q < NQ; q++) {
                 if (q < q_end) {
                     const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
                     const unsigned xl = x & 0xFFFFu, xh = x >> 16;
@@ -487,8 +489,9 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
         const u16x2 one = k16_opaque_ones();
         const u16x2 tr = k16_splat(sm.t1[rr]);
         unsigned char *mb = reinterpret_cast<unsigned char *>(sm.hist);
+        constexpr int MBS = 4 * NQ + 16;                    // bytes per row (144 for 1024 columns: the sixteen rows of a wave instruction meet two to a bank)
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < NQ / 4; q++) {
             const int piece = jj + 16 * q;
             const uint4 tc = sm.tcol[piece];
             const unsigned tcv[4] = {tc.x, tc.y, tc.z, tc.w};
@@ -501,11 +504,17 @@ __global__ __launch_bounds__(R16_THREADS, 8) void r16_select_kernel(const uint16
                     acc |= k16_to_u32(f) << (2 * d);
                 }
             }
-            mb[rr * 144 + piece] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);        // (144: the sixteen rows of a wave instruction meet two to a bank)
+            mb[rr * MBS + piece] = (unsigned char)((acc | (acc >> 15)) & 0xFFu);
         }
         lds_barrier();
-        if (t < 8 * R16_LINES && l0 + (t >> 3) < M)
-            reinterpret_cast<uint4 *>(bits)[((int64_t)p * w.max_m + l0) * 8 + t] = reinterpret_cast<const uint4 *>(mb)[(t >> 3) * 9 + (t & 7)];
+        constexpr int RQ = NQ / 4;                          // 16-byte runs per row that hold columns (NQ / 2 words); the row's other words: zero
+        const int rsh = wpr == 16 ? 3 : 4;                  // a row of the mask: wpr / 2 runs
+        for (int u = t; u < (R16_LINES << rsh); u += R16_THREADS) {
+            const int row = u >> rsh, part = u & ((1 << rsh) - 1);
+            if (l0 + row < M)
+                reinterpret_cast<uint4 *>(bits)[(((int64_t)p * w.max_m + l0) << rsh) + u] =
+                    part < RQ ? reinterpret_cast<const uint4 *>(mb)[row * (MBS / 16) + part] : make_uint4(0u, 0u, 0u, 0u);
+        }
     }
 }
 
@@ -680,7 +689,7 @@ __global__ __launch_bounds__(64) void r16_exact_extra_kernel(const FT *__restric
 
 // ---- the cells the items select, where the other side selects them too (lane = item) ---------------------------------------------------
 __global__ __launch_bounds__(64) void r16_apply_kernel(const uint16_t *__restrict__ keys, const acoss_pair_desc *__restrict__ descs,
-                                                       R16Work w, int ldm, int ldn, int mutual, uint64_t *__restrict__ bits)
+                                                       R16Work w, int ldm, int ldn, int mutual, uint64_t *__restrict__ bits, int wpr)
 {
     const int total = min(w.static_items + w.counters[0], w.item_cap);
     for (int s = blockIdx.x * 64 + threadIdx.x; s < total; s += 64 * gridDim.x) {
@@ -707,7 +716,7 @@ __global__ __launch_bounds__(64) void r16_apply_kernel(const uint16_t *__restric
                     for (int m = 0; m < min(o->n, R16_CAP); m++) other |= ((osel >> m) & 1) && (int)o->pos[m] == want;
                 }
             }
-            if (other) atomicOr(reinterpret_cast<unsigned long long *>(bits) + ((int64_t)p * w.max_m + i) * 16 + (j >> 6), 1ull << (j & 63));
+            if (other) atomicOr(reinterpret_cast<unsigned long long *>(bits) + ((int64_t)p * w.max_m + i) * wpr + (j >> 6), 1ull << (j & 63));
         }
     }
 }
@@ -764,17 +773,29 @@ int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t 
     if (kappa == 0.0) { kv = 0.0; mode = 2; } else if (kappa < 1.0) { kv = kappa; mode = 0; } else { kv = kappa; mode = 1; }
     const int cb = ceil_div(max_n, R16_LINES), rb = ceil_div(max_m, R16_LINES);
     if ((int64_t)K * cb > 0x7fffffffLL || (int64_t)K * rb > 0x7fffffffLL) { set_error("radix16: batch too large"); return ACOSS_ENOTSUP; }
+    if (max_m > 2048 || max_n > 2048) { set_error("radix16: matrices up to 2048 x 2048"); return ACOSS_ENOTSUP; }
+    // long forms (a side beyond 1024): 48 or 64 dwords of keys per thread; 32 words per row of the mask when either side is long
+    const int wpr = mask_bits_words(max_m, max_n);
     if (what & 1) {
         ACOSS_HIP(hipMemsetAsync(w.counters, 0, 256, st));
         ACOSS_HIP(hipMemsetAsync(w.pair_flag, 0, (size_t)K, st));
         if (mutual) {
-            hipLaunchKernelGGL(r16_select_kernel<1>, dim3((unsigned)((int64_t)K * cb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, cb, band, koff, mutual, bits, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
+#define R16_LAUNCH_SELECT(DIR_, NQ_, blocks_, tiles_, item0_, dbg_)                                                                              \
+    hipLaunchKernelGGL((r16_select_kernel<DIR_, NQ_>), dim3((unsigned)(blocks_)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, \
+                       ldn, tiles_, band, koff, mutual, bits, wpr, item0_, dbg_)
+            const int nq = max_m <= 1024 ? 32 : (max_m <= 1536 ? 48 : 64);         // dwords of keys per thread: the columns' positions are rows
+            if (nq == 32) R16_LAUNCH_SELECT(1, 32, (int64_t)K * cb, cb, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
+            else if (nq == 48) R16_LAUNCH_SELECT(1, 48, (int64_t)K * cb, cb, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
+            else R16_LAUNCH_SELECT(1, 64, (int64_t)K * cb, cb, R16_TILE_ITEMS * K * rb, (what >> 8) & 15);
             const int rc = launch_check("r16_select_kernel<columns>");
             if (rc) return rc;
         } else ACOSS_HIP(hipMemsetAsync(w.tile_used + (size_t)K * rb, 0, (size_t)K * cb * sizeof(int), st));
     }
     if (what & 2) {
-        hipLaunchKernelGGL(r16_select_kernel<0>, dim3((unsigned)((int64_t)K * rb)), dim3(R16_THREADS), 0, st, keys16, descs, win, kv, mode, w, ldm, ldn, rb, band, koff, mutual, bits, 0, (what >> 12) & 15);
+        const int nq = max_n <= 1024 ? 32 : (max_n <= 1536 ? 48 : 64);
+        if (nq == 32) R16_LAUNCH_SELECT(0, 32, (int64_t)K * rb, rb, 0, (what >> 12) & 15);
+        else if (nq == 48) R16_LAUNCH_SELECT(0, 48, (int64_t)K * rb, rb, 0, (what >> 12) & 15);
+        else R16_LAUNCH_SELECT(0, 64, (int64_t)K * rb, rb, 0, (what >> 12) & 15);
         const int rc = launch_check("r16_select_kernel<rows>");
         if (rc) return rc;
     }
@@ -782,7 +803,7 @@ int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t 
         hipLaunchKernelGGL(r16_exact_tiles_kernel<FT>, dim3(8192), dim3(64), 0, st, feats, norms, d, descs, win, w, K * rb, rb, cb);
         hipLaunchKernelGGL(r16_exact_extra_kernel<FT>, dim3(256), dim3(64), 0, st, feats, norms, d, descs, win, w);
         if (what & 64) return launch_check("r16_exact_tiles_kernel");
-        hipLaunchKernelGGL(r16_apply_kernel, dim3(4096), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits);
+        hipLaunchKernelGGL(r16_apply_kernel, dim3(4096), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits, wpr);
         hipLaunchKernelGGL(r16_flag_list_kernel, dim3(1), dim3(256), 0, st, w, K);
         const int rc = launch_check("r16_exact_kernel / r16_apply_kernel");
         if (rc) return rc;
@@ -806,7 +827,7 @@ extern "C" int acoss_radix16_stage(int what, const uint16_t *keys16, const float
         return ACOSS_EINVAL;
     }
     const int max_m = max_nx - win + 1, max_n = max_ny - win + 1;
-    if (max_m > 1024 || max_n > 1024) { set_error("radix16_stage: matrices up to 1024 x 1024"); return ACOSS_ENOTSUP; }
+    if (max_m > 2048 || max_n > 2048) { set_error("radix16_stage: matrices up to 2048 x 2048"); return ACOSS_ENOTSUP; }
     if (work_bytes < acoss_radix16_work_bytes(K, max_nx, max_ny, win)) { set_error("radix16_stage: workspace too small"); return ACOSS_EINVAL; }
     if (K == 0) return ACOSS_OK;
     return r16_run<double>(what, keys16, band, koff, feats, norms, d, descs, K, win, max_nx, max_ny, kappa, mutual, bits, work, (hipStream_t)stream);

@@ -93,6 +93,7 @@ static int pair_class(const acoss_corpus *c, int win, int i, int j)
 
 struct BatchPlan {
     int cls;
+    bool exact = false;         // (class 1) the float64 path, whatever the handle's switches say: pairs the 16-bit keys left unresolved
     std::vector<int> idx;       // positions in the caller's pair list
     int max_nx, max_ny;
 };
@@ -320,7 +321,8 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
     if (rc != ACOSS_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     // pinned staging: every batch's descriptors and bands (read by asynchronous copies until the stream gets there), the scores
-    const size_t pin_descs = al(sizeof(acoss_pair_desc) * (size_t)K), pin_band = al(8 * (size_t)K), pin_scores = al(12 * (size_t)K), pin_koff = al(4 * (size_t)K);
+    // (twice K: pairs of 1033 .. 2056 frames the 16-bit keys leave unresolved -- exact ties -- come round again in batches of their own)
+    const size_t pin_descs = al(sizeof(acoss_pair_desc) * 2 * (size_t)K), pin_band = al(16 * (size_t)K), pin_scores = al(24 * (size_t)K), pin_koff = al(8 * (size_t)K);
     rc = pin_reserve(c, pin_descs + pin_band + pin_scores + pin_koff);
     if (rc != ACOSS_OK) return rc;
     acoss_pair_desc *h_descs = (acoss_pair_desc *)c->pin;
@@ -331,7 +333,9 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
     const size_t avail = scratch_bytes - (size_t)(base - (char *)scratch);
     const int nq = (want & 1) ? 1 : 0, nd = (want & 2) ? 1 : 0, ns = (want & 4) ? 1 : 0;
     size_t done = 0;
-    for (const BatchPlan &b : plan) {
+    std::vector<int32_t> unresolved;
+    for (size_t bi = 0; bi < plan.size(); bi++) {
+        const BatchPlan b = plan[bi];                   // (a copy: the loop appends to `plan`)
         const int B = (int)b.idx.size(), cls = b.cls;
         std::vector<int32_t> bp(2 * (size_t)B);
         for (int t = 0; t < B; t++) { bp[2 * (size_t)t] = pairs[2 * b.idx[(size_t)t]]; bp[2 * (size_t)t + 1] = pairs[2 * b.idx[(size_t)t] + 1]; }
@@ -345,7 +349,10 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
         float *d_band = (float *)(base + v.band), *d_scores = (float *)(base + v.scores);
         ACOSS_HIP(hipMemcpyAsync(d_descs, hd, sizeof(acoss_pair_desc) * (size_t)B, hipMemcpyHostToDevice, st));
         if (do_oti) { rc = acoss_oti_batch(c->gchroma, c->nbins, d_descs, B, st); if (rc) return rc; }
-        const bool use32 = cls == 0 && c->f32_ok && !c->force_f64;
+        // 16-bit keys up to 2048 x 2048: class 1 takes them when the radix selection is on (its long form; the wave-per-row kernels
+        // behind it stop at 1024)
+        const bool long16 = cls == 1 && !b.exact && c->f32_ok && !c->force_f64 && c->keys16 && acoss_radix16_enabled();
+        const bool use32 = (cls == 0 && c->f32_ok && !c->force_f64) || long16;
         uint64_t *bits = (uint64_t *)(base + v.bits);
         if (cls <= 1) {
             if (use32) {
@@ -397,6 +404,23 @@ int acoss_serra09_scores(acoss_corpus *c, const int32_t *pairs, int K, int win, 
             else if (nd) rc = acoss_align_bits_batch(1, bits, d_descs, B, win, b.max_nx, b.max_ny, 1, nullptr, d_scores + B, st);
             if (!rc && ns) rc = acoss_align_bits_batch(2, bits, d_descs, B, win, b.max_nx, b.max_ny, 0, nullptr, d_scores + 2 * B, st);
             if (rc) return rc;
+            if (long16) {
+                // pairs the radix selection could not express: once more, on the float64 path, in a batch of their own (it is a
+                // subset of this one: the scratch fits); their scores overwrite the ones just computed from undefined masks
+                unresolved.resize((size_t)B);
+                int n_un = 0;
+                rc = acoss_mask_bits_keys16_unresolved(base + v.work, B, b.max_nx, b.max_ny, win, unresolved.data(), B, &n_un, st);
+                if (rc) return rc;
+                if (n_un > 0) {
+                    BatchPlan r;
+                    r.cls = 1;
+                    r.exact = true;
+                    r.max_nx = b.max_nx;
+                    r.max_ny = b.max_ny;
+                    for (int t = 0; t < n_un; t++) r.idx.push_back(b.idx[(size_t)unresolved[(size_t)t]]);
+                    plan.push_back(std::move(r));
+                }
+            }
         } else {
             // byte mask: long songs (fused strip kernel, any-length selection) or shapes without a fused kernel (one kernel per function)
             double *T = (double *)(base + v.T);

@@ -31,11 +31,11 @@ struct ThreshWork {
     int4 *side_slots;       // {pair, direction, index, high word the selection left}
     uint32_t *side_keys;    // [side_cap][1024]
     int side_cap;
-    void *radix;            // (bit-mask path up to 1024 x 1024) the radix selection's workspace: r16_work_layout(radix, K, max_m, max_n)
+    void *radix;            // (bit-mask path up to 2048 x 2048) the radix selection's workspace: r16_work_layout(radix, K, max_m, max_n)
     __host__ __device__ uint64_t *col_word(int p, int j, int e) const { return col_bits + ((size_t)p * wpr + e) * max_n + j; }
 };
 
-// ---- workspace of the radix selection (radix16.h lays it out; up to 1024 x 1024 only): behind the side buffer ---------------------
+// ---- workspace of the radix selection (radix16.h lays it out; up to 2048 x 2048): behind the side buffer / the bit planes ---------------------
 // Every tile of lines owns R16_TILE_ITEMS item slots, one for four lines (no global atomic on the selection kernels' path; 4 % of
 // the lines need an item on the benchmark, 15-25 % on temporally smooth features); a tile with more asks for single items behind
 // them: room for 2 % of the lines.
@@ -88,6 +88,8 @@ inline size_t thresh_work_bytes(int K, int max_m, int max_n, bool with_bits)
         b += (size_t)K * (size_t)(max_m + max_n) * mask_bits_words(max_m, max_n) * sizeof(uint64_t) + 64;
         if (mask_bits_words(max_m, max_n) == 16)
             b += 512 + (size_t)thresh_side_cap(K, max_m, max_n) * (sizeof(int4) + 1024 * sizeof(uint32_t)) + 256 + r16_work_bytes(K, max_m, max_n);
+        else if (max_m <= 2048 && max_n <= 2048)
+            b += 512 + r16_work_bytes(K, max_m, max_n);
     }
     return b;
 }
@@ -123,6 +125,9 @@ inline ThreshWork thresh_work_layout(void *work, int K, int max_m, int max_n, bo
             w.side_slots = (int4 *)(a + 256);
             w.side_keys = (uint32_t *)(a + 256 + (size_t)w.side_cap * sizeof(int4));
             w.radix = (void *)(((uintptr_t)(w.side_keys + (size_t)w.side_cap * 1024) + 255) & ~(uintptr_t)255);
+        } else if (max_m <= 2048 && max_n <= 2048) {
+            // (long form of the 16-bit keys: the radix selection alone -- no side buffer, the bit planes stay unused)
+            w.radix = (void *)(((uintptr_t)(w.col_bits + (size_t)K * max_n * w.wpr) + 255) & ~(uintptr_t)255);
         }
     }
     return w;

@@ -451,6 +451,19 @@ def mask_bits_keys16(keys16, band, koff, xp32, corpus, batch, kappa, mutual=True
     return out, work
 
 
+def mask_bits_keys16_unresolved(work, batch):
+    """Pairs of the batch the last mask_bits_keys16() call on `work` left unresolved (int32 ndarray; synchronises).  Matrices up
+    to 1024 x 1024: always empty; beyond (the long form of the radix selection, up to 2048 x 2048): pairs with exact ties --
+    their masks are undefined and the caller takes them through mask_bits() on the float64 sums."""
+    import ctypes
+    lst = np.zeros(max(batch.K, 1), dtype=np.int32)
+    n = ctypes.c_int(0)
+    check(_lib.load().acoss_mask_bits_keys16_unresolved(_ptr(work), batch.K, batch.max_nx, batch.max_ny, batch.win,
+                                                        lst.ctypes.data_as(ctypes.c_void_p), batch.K, ctypes.byref(n), _stream()),
+          "mask_bits_keys16_unresolved")
+    return lst[:n.value].copy()
+
+
 def radix16_work(batch):
     """Workspace of radix16_stage() for this batch (uint8 device tensor)."""
     need = int(_lib.load().acoss_radix16_work_bytes(batch.K, batch.max_nx, batch.max_ny, batch.win))

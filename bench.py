@@ -769,6 +769,7 @@ def extras_variant(kind, corpus_h, headline, engine, synth, oracle, threads, tor
     kind "hpcp_f32": the config-2 corpus cast to float32 -- the metric's literal dtype: essentia HPCP is float32 (Serra09.py:101;
         get_csm then follows its inputs' dtype, CRPUtils.py:82, and sliding_csm squares in that dtype before it promotes, :40-41);
         the float32-corpus filter path (the corpus itself is the filter's operand);
+    kind "frames_1200": config 2's corpus with 1200-frame songs (the size class behind the first: 1033 .. 2056 frames);
     kind "smooth": config 2's shape with temporally correlated frame noise (AR(1), rho = 0.9: synth.config2_smooth), float64 --
         neighbouring cells of a row are then nearly equal, which is what real chroma looks like from frame to frame.
     Scores of a sample are compared with the oracle's chain on the same inputs."""
@@ -777,6 +778,11 @@ def extras_variant(kind, corpus_h, headline, engine, synth, oracle, threads, tor
         ch = corpus_h
         feats = np.ascontiguousarray(ch.feats, dtype=np.float32)
         what = "the config-2 corpus as float32 (%d songs x %d frames x 12)" % (ch.n_songs, ch.song(0).shape[0])
+    elif kind == "frames_1200":
+        ch = synth.config2(n_songs=256, n_frames=1200)
+        feats = ch.feats
+        what = ("synth.config2 with 1200-frame songs (256 of them, float64): matrices of 1192 x 1192 -- beyond the 1024 the wave-per-row "
+                "selection stops at; the long form of the radix selection (64 dwords of keys per thread)")
     else:
         ch = synth.config2_smooth(n_songs=256, n_frames=corpus_h.song(0).shape[0])
         feats = ch.feats
@@ -1250,6 +1256,7 @@ def main():
         plugin_rate = out["plugin"]["value"]
         for key, fn in (("hpcp_f32", lambda: extras_variant("hpcp_f32", corpus_h, plugin_rate, engine, synth, oracle, threads, torch)),
                         ("smooth", lambda: extras_variant("smooth", corpus_h, plugin_rate, engine, synth, oracle, threads, torch)),
+                        ("frames_1200", lambda: extras_variant("frames_1200", corpus_h, plugin_rate, engine, synth, oracle, threads, torch)),
                         ("full_job", lambda: extras_full_job(corpus_h, torch, tmpdir)),
                         ("plugin_similarity", lambda: extras_plugin_similarity(corpus_h, all_pairs, oracle, threads, torch, tmpdir)),
                         ("scatter_chain", lambda: extras_scatter_chain(engine, oracle, torch)),

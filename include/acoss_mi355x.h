@@ -330,6 +330,17 @@ int acoss_mask_bits_keys16_f32_batch(const uint16_t *keys16, const float *band, 
  * work items beyond the tiles' own slots, out[1] rows + columns that flagged their pair, out[2] pairs handed to the
  * wave-per-row kernels, out[3] reserved, out[8 .. 19] why lines flagged their pair (development statistics).  out: 20 ints. */
 int acoss_mask_bits_keys16_stats(void *work, int K, int max_nx, int max_ny, int win, int *out);
+/* Matrices with a side of 1025 .. 2048 (round 5: the long form of the radix selection, 64 dwords of keys per thread; needs
+ * ACOSS_RADIX16 on, the default -- acoss_radix16_enabled()): acoss_mask_bits_keys16(_f32)_batch runs the radix selection alone,
+ * and the pairs it cannot express (exact ties: more cells inside the reach of a row's k-th smallest key than a work item
+ * holds; thresholds below the key range) stay UNRESOLVED -- their rows of `bits` are undefined.  This call waits for `stream`
+ * and lists them: *n pairs (indices into the batch; at most `cap` are written to `list`).  The caller redoes them on the float64
+ * path (acoss_crp_planar_batch_f64 + acoss_mask_bits_planar_batch), as acoss_serra09_scores does.  Matrices up to 1024 x 1024:
+ * *n = 0 always (the call does not wait). */
+int acoss_mask_bits_keys16_unresolved(void *work, int K, int max_nx, int max_ny, int win, int32_t *list, int cap, int *n,
+                                      void *stream);
+/* 1 unless the environment variable ACOSS_RADIX16 is "0", "false", "no" or empty (read at every call). */
+int acoss_radix16_enabled(void);
 /* Round 5: the selection of acoss_mask_bits_keys16_batch as a two-pass radix selection with the keys in registers
  * (csrc/radix16_kernels.hip) -- the form acoss_mask_bits_keys16_batch itself runs; these are its stages, exposed for the
  * per-kernel measurements of bench.py and the stage tests.  `what` is a bit set: 1 = the column kernel (every column's bound

@@ -154,3 +154,59 @@ def test_exact_ties_hand_their_pairs_back(eng):
         new, st = _masks(eng, k16, band, koff, xp32, corpus, batch, 0.095, mutual, radix=True)
         assert 0 < st[2] < batch.K, st                      # some pairs handed back, not all
         assert torch.equal(new, want), (mutual, st)
+
+
+def _byte_mask(B, batch, p):
+    d = batch.descs[p]
+    M, N = int(batch.M[p]), int(batch.N[p])
+    return B[int(d["crp_off"]):int(d["crp_off"]) + M * int(d["crp_pitch"])].cpu().numpy().reshape(M, -1)[:, :N]
+
+
+def test_long_form_up_to_2048(eng):
+    """Songs of 1033 .. 2056 frames (a side of 1025 .. 2048): the radix selection with 64 dwords of keys per thread, 32-word mask
+    rows.  Masks as the float64 path's for every pair it resolves -- all of them on tie-free features, both one-sided and mutual."""
+    import torch
+    from acoss_amd import synth
+    lens = iter([2056, 1033, 300, 1500, 9, 1990, 1040, 1100])
+    ch = synth.make_corpus(4, 2, seed=29, lengths=lambda r: next(lens))
+    corpus = eng.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
+    pairs = np.array([(i, j) for i in range(8) for j in range(8)], dtype=np.int32)
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    assert eng.bits_words(batch) == 32
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    xp32, koff, band, k16 = _chain(eng, corpus, batch)
+    for mutual in (True, False):
+        for kappa in (0.095, 0.4, 7):
+            B = eng.binarize(T, batch, kappa, mutual=mutual)           # (bit-serial selection on the float64 sums, byte mask)
+            new, st = _masks(eng, k16, band, koff, xp32, corpus, batch, kappa, mutual, radix=True)
+            assert st[2] == 0, st
+            for p in range(batch.K):
+                assert np.array_equal(eng.unpack_mask_bits(new, batch, p), _byte_mask(B, batch, p)), (mutual, kappa, p, st)
+
+
+def test_long_form_lists_the_pairs_it_cannot_express(eng):
+    """Periodic 1500-frame songs (exact ties by the hundred): their pairs are listed as unresolved, the others' masks are the
+    float64 path's; the scorer (acoss_serra09_scores) redoes the listed pairs on the float64 path -- tests/test_gpu_scorer.py."""
+    import torch
+    from acoss_amd import synth
+    rng = np.random.default_rng(6)
+    pat = rng.random((7, 12)) + 0.1
+    A = np.tile(pat, (215, 1))[:1500]
+    ch = synth.make_corpus(3, 1, seed=31, lengths=lambda r: int(r.integers(1100, 1400)))
+    feats = np.concatenate([A, ch.feats])
+    off = np.concatenate([[0, len(A)], len(A) + ch.frame_off[1:]]).astype(np.int64)
+    gc = np.concatenate([(A.sum(0) / A.sum(0).max())[None, :], ch.gchroma])
+    corpus = eng.DeviceCorpus(feats, off, gchroma=gc)
+    pairs = np.array([(i, j) for i in range(4) for j in range(4)], dtype=np.int32)
+    batch = eng.PairBatch(corpus.frame_off, pairs, 9, corpus.device, pitch_align=32)
+    eng.oti(corpus, batch)
+    T = eng.crp(corpus, batch, eng.pack_x(corpus, batch))
+    xp32, koff, band, k16 = _chain(eng, corpus, batch)
+    B = eng.binarize(T, batch, 0.095, mutual=True)
+    bits, work = eng.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095, mutual=True)
+    un = set(int(p) for p in eng.mask_bits_keys16_unresolved(work, batch))
+    assert un and 0 in un and len(un) < batch.K, un             # song 0 against itself: ties everywhere
+    for p in range(batch.K):
+        if p not in un:
+            assert np.array_equal(eng.unpack_mask_bits(bits, batch, p), _byte_mask(B, batch, p)), p

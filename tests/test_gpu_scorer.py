@@ -77,6 +77,40 @@ def test_scorer_size_classes_and_smith_waterman(lib, orc):
             assert abs(s[t] - so) <= 1e-5, (t, s[t], so)
 
 
+def test_scorer_long_songs_with_exact_ties_come_round_again(lib, orc):
+    """Songs of 1033 .. 2056 frames take the 16-bit keys' long form (round 5); a periodic song's pairs hold exact ties by the
+    hundred, the radix selection lists them as unresolved and the scorer scores them again on the float64 path: every pair
+    equals the oracle, with the radix selection on and off."""
+    from acoss_amd import synth
+    rng = np.random.default_rng(12)
+    pat = rng.random((7, 12)) + 0.1
+    A = np.tile(pat, (200, 1))[:1300]
+    ch = synth.make_corpus(3, 1, seed=77, lengths=lambda r: int(r.integers(1040, 1300)))
+    feats = np.concatenate([A, ch.feats])
+    off = np.concatenate([[0, len(A)], len(A) + ch.frame_off[1:]]).astype(np.int64)
+    gc = np.concatenate([(A.sum(0) / A.sum(0).max())[None, :], ch.gchroma])
+    pairs = np.array([(0, 1), (1, 2), (0, 0), (2, 3), (3, 0), (3, 1)], dtype=np.int32)
+    free = [1, 3, 5]                # (pairs with the periodic song: which of a line's equal values np.argpartition takes is numpy's
+                                    #  choice -- CRPUtils.py:192; here the lowest positions, and the float64 path is the reference)
+    want_q, want_d = zip(*[orc.serra09_pair(feats[off[i]:off[i + 1]], gc[i], feats[off[j]:off[j + 1]], gc[j]) for i, j in pairs[free]])
+    old = {k: os.environ.get(k) for k in ("ACOSS_RADIX16", "ACOSS_PLANAR32")}
+    try:
+        os.environ["ACOSS_PLANAR32"] = "0"                      # the float64 keys for every pair
+        q64, d64, _ = _scores(lib, feats, off, gc, pairs, want=3)
+        os.environ.pop("ACOSS_PLANAR32")
+        assert np.array_equal(q64[free], np.array(want_q)) and np.array_equal(d64[free], np.array(want_d))
+        for flag in ("1", "0"):
+            os.environ["ACOSS_RADIX16"] = flag
+            q, d, _ = _scores(lib, feats, off, gc, pairs, want=3)
+            assert np.array_equal(q, q64) and np.array_equal(d, d64), flag
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
 def test_scorer_other_widths_windows_and_errors(lib, orc):
     """20-dimensional features and a window of 5 have no fused kernel: one kernel per function, all three recurrences
     (the advisor's case: a silent zero for swc there).  Bad indices and short songs are errors, not zeros."""
