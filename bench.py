@@ -21,7 +21,7 @@ Prints ONE JSON line on rank 0.  `roofline` describes the strip kernel of the ti
 sliding-window kernel -- timed live with HIP events on the launch stream inside the timed region (`stage_ms` has every stage);
 `roofline_selection.rows` / `.cols` the two selection kernels that read its output, each launched alone where it runs in the
 chain.  Beside each live block: the same kernel's average in the committed rocprofv3 summary (`profiles_avg_launch_ms`,
-`profiles_frac`), when profiles/r04_profile_meta.json names this workload.  The key matrix lives in a plain allocation
+`profiles_frac`), when profiles/r05_profile_meta.json names this workload.  The key matrix lives in a plain allocation
 (ACOSS_BENCH_ARENA_GB=<n> scans the windows of an n-GB arena for the fastest one first: rounds 2-3's placement study, opt-in).
 Beside the headline (rank 0, one GPU; `--no-extras` skips them): `roofline_csm_*` = the stand-alone get_csm kernels;
 `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores and whether the GPU scores of the sampled pairs are
@@ -328,11 +328,11 @@ def time_kernel(fn, torch, reps=5):
 
 def profile_file(suffix):
     """The newest committed profile artefact profiles/rNN_<suffix> (tools/collect_profiles.sh + tools/adopt_profiles.py)."""
-    for tag in ("r04", "r03"):
+    for tag in ("r05", "r04", "r03"):
         f = os.path.join(ROOT, "profiles", "%s_%s" % (tag, suffix))
         if os.path.exists(f):
             return f
-    return os.path.join(ROOT, "profiles", "r04_%s" % suffix)
+    return os.path.join(ROOT, "profiles", "r05_%s" % suffix)
 
 
 def pmc_traffic(path, kernel_key, P, frames):
@@ -389,7 +389,8 @@ def attach_profile_averages(out, P, args):
     for blk in blocks:
         if not blk:
             continue
-        key = blk["kernel"].split(" ")[0]
+        import re
+        key = re.match(r"^[A-Za-z0-9_:]+(<[^>]*>)?", blk["kernel"]).group(0)
         key = {"crp_rows32_kernel<12,1>": "crp_rows32_kernel<12, 1>", "crp_rows32_kernel<12,0>": "crp_rows32_kernel<12, 0>",
                "crp_strip32_kernel<12>": "crp_strip32_kernel<12, 0>"}.get(key, key)
         ms = find(key)
@@ -1116,7 +1117,7 @@ def main():
                         xk.append(ev[2].elapsed_time(ev[3]))
                 t_rowk, t_colk, t_exact = float(np.median(rk)), float(np.median(ck)), float(np.median(xk))
                 del rwork
-                rname, cname = "r16_select_kernel<rows> (+ the mask's base bits)", "r16_select_kernel<columns>"
+                rname, cname = "r16_select_kernel<0, 32> (rows, + the mask's base bits)", "r16_select_kernel<1, 32> (columns)"
             else:
                 planes = runner.S.view(torch.int32)[:engine.planar_elems(b)]
                 engine.crp_planar32(corpus, b, engine.pack_x32(corpus, b, out=runner.xp), out=planes)
@@ -1264,10 +1265,12 @@ def main():
                         ("early_snf", lambda: extras_early_snf(engine, synth, torch)),
                         ("ftm2d", lambda: extras_ftm2d(engine, torch)),
                         ("scatter_csm", lambda: extras_scatter_csm(engine, oracle, torch))):
+            t_blk = time.perf_counter()
             try:
                 out[key] = fn()
             except Exception as exc:           # a side block must not take the headline down
                 out[key] = {"error": "%s: %s" % (type(exc).__name__, exc)}
+            out.setdefault("side_block_seconds", {})[key] = round(time.perf_counter() - t_blk, 2)
             engine.release_scratch()
             torch.cuda.empty_cache()
         import shutil

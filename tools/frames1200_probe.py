@@ -1,5 +1,5 @@
 """1200-frame songs through the scorer: the long form of the radix selection (round 5) against the float64 planar keys it
-replaces for this size class (ACOSS_RADIX16=0).  usage: python tools/frames1200_probe.py [frames] [pairs]"""
+replaces for this size class (ACOSS_RADIX16=0).  usage: python tools/frames1200_probe.py [frames] [pairs] [ragged]"""
 import os, sys, time
 import numpy as np
 import torch
@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth
 frames = int(sys.argv[1]) if len(sys.argv) > 1 else 1200
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 16384
-ch = synth.config2(n_songs=256, n_frames=frames)
+if "ragged" in sys.argv:          # lengths across the size class (and a few below it: mixed batches)
+    ch = synth.make_corpus(40, 4, seed=frames, lengths=lambda r: int(r.integers(900, 2057)))
+else:
+    ch = synth.config2(n_songs=256, n_frames=frames)
 corpus = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
 allp = synth.all_pairs(ch.n_songs)
 sel = allp[np.random.default_rng(2).permutation(len(allp))[:P]]
