@@ -594,7 +594,7 @@ static int mask_bits_keys16_impl(const uint16_t *keys16, const float *band, cons
             if (d == 12) hipLaunchKernelGGL(select_cols_k16_list_kernel<12>, dim3((unsigned)(slots * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx, list, list_n, slots);
             else hipLaunchKernelGGL(select_cols_k16_list_kernel<13>, dim3((unsigned)(slots * cb)), dim3(64 * K16_COL_WAVES), 0, st, keys16, descs, win, kv, mode, w, cb, cx, list, list_n, slots);
         }
-        hipLaunchKernelGGL(select_fix_side16_kernel<FT>, dim3(256), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);
+        hipLaunchKernelGGL(select_fix_side16_kernel<FT>, dim3(2048), dim3(64), 0, st, feats, norms, d, descs, win, kv, mode, w, koff);      // (grid-stride over the slots asked for)
         const int gm2 = ceil_div(max_m, 64), gn2 = ceil_div(max_n, 64);
         hipLaunchKernelGGL((select_fix_k16_kernel<0, FT>), dim3(256), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gm2, (int64_t)K * gm2, list, list_n);
         if (mutual) hipLaunchKernelGGL((select_fix_k16_kernel<1, FT>), dim3(256), dim3(64), 0, st, keys16, feats, norms, d, descs, win, kv, mode, w, koff, gn2, (int64_t)K * gn2, list, list_n);

@@ -133,7 +133,9 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
     if ((incl - c < need) & (need <= incl)) sm.dec[line] = (unsigned)e | ((unsigned)(need - (incl - c)) << 8) | ((unsigned)(incl - c) << 20);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     const unsigned d1 = sm.dec[line];
-    bool ok = (d1 != 0x7FFFFFFFu) & (B > 0);
+    // (B == 0, a threshold in the lowest 256 keys: the window starts at key -1, which no cell has -- the 0xFFFF pads behind a
+    //  line's end land on x == 0 there; the reach of a key never goes below key 0, so x == 0 is never read for such a line)
+    const bool ok = d1 != 0x7FFFFFFFu;
     const int sstar = (int)(d1 & 15u), r = (int)((d1 >> 8) & 0xFFFu), cums = (int)(d1 >> 20) & 0xFFF;
     const int fq = line >> 2, fs = 8 * (line & 3);
     constexpr int FW = R16_LINES / 4;
@@ -801,7 +803,7 @@ int r16_run(int what, const uint16_t *keys16, const float *band, const uint32_t 
     }
     if (what & 4) {
         hipLaunchKernelGGL(r16_exact_tiles_kernel<FT>, dim3(8192), dim3(64), 0, st, feats, norms, d, descs, win, w, K * rb, rb, cb);
-        hipLaunchKernelGGL(r16_exact_extra_kernel<FT>, dim3(256), dim3(64), 0, st, feats, norms, d, descs, win, w);
+        hipLaunchKernelGGL(r16_exact_extra_kernel<FT>, dim3(2048), dim3(64), 0, st, feats, norms, d, descs, win, w);      // (none on the benchmark; smooth features: 10^5 items)
         if (what & 64) return launch_check("r16_exact_tiles_kernel");
         hipLaunchKernelGGL(r16_apply_kernel, dim3(4096), dim3(64), 0, st, keys16, descs, w, ldm, ldn, mutual, bits, wpr);
         hipLaunchKernelGGL(r16_flag_list_kernel, dim3(1), dim3(256), 0, st, w, K);
