@@ -29,8 +29,7 @@ struct __attribute__((aligned(16))) R16Item {
 struct R16Work {
     uint16_t *t1_row, *t1_col;           // [K][max_m], [K][max_n]
     int *item_row, *item_col;
-    int *counters;                       // [0] items beyond the tiles' own slots, [1] lines that flagged their pair (statistics), [2] pairs in pair_list, [3] items in item_list
-    int *item_list;                      // the items of unflagged pairs, compacted (r16_item_list_kernel)
+    int *counters;                       // [0] items beyond the tiles' own slots, [1] lines that flagged their pair (statistics), [2] pairs in pair_list, [8 + why] why lines flagged their pair
     int *tile_used;                      // [row tiles of every pair][column tiles of every pair]: items in the tile's R16_TILE_ITEMS slots
     int static_items;                    // R16_TILE_ITEMS x tiles: item index = R16_TILE_ITEMS * tile + slot; the rest of `items` is asked for one by one
     int *pair_list;                      // [K]: the flagged pairs, compacted (r16_flag_list_kernel)
@@ -55,7 +54,6 @@ inline R16Work r16_work_layout(void *work, int K, int max_m, int max_n)
     w.pair_list = (int *)a;                 a += r16_align((size_t)K * sizeof(int));
     w.pair_flag = (unsigned char *)a;       a += r16_align((size_t)K);
     w.tile_used = (int *)a;                 a += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
-    w.item_list = (int *)a;                 a += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
     w.items = (R16Item *)a;
     w.item_cap = r16_item_cap(K, max_m, max_n);
     w.static_items = R16_TILE_ITEMS * r16_tiles(K, max_m, max_n);

@@ -181,15 +181,6 @@ static int plan_batches(const acoss_corpus *c, const int32_t *pairs, int K, int 
 
 static int pitch_of(int cls) { return cls <= 1 ? 32 : 16; }
 
-// upper bound of the matrix elements of a batch without planning it: every pair at the batch's largest shape
-static void batch_elems(const BatchPlan &b, int win, int64_t &csm, int64_t &crp)
-{
-    const int pa = pitch_of(b.cls);
-    const int64_t pc = ((int64_t)b.max_ny + pa - 1) / pa * pa, pr = ((int64_t)(b.max_ny - win + 1) + pa - 1) / pa * pa;
-    csm = (int64_t)b.idx.size() * ((int64_t)b.max_nx * pc + pa);
-    crp = (int64_t)b.idx.size() * ((int64_t)(b.max_nx - win + 1) * pr + pa);
-}
-
 }  // namespace acoss
 
 using namespace acoss;
@@ -217,10 +208,13 @@ int acoss_corpus_wrap(const double *feats, const double *norms, const double *gc
     c->n32 = const_cast<float *>(n32);
     c->f32_ok = f32 && n32 && norms_scaled;
     // the two switches of the product chain (README.md, "Switches"), read once, when the handle is made
-    const char *env = getenv("ACOSS_PLANAR32");
-    c->force_f64 = env && strcmp(env, "0") == 0;
-    const char *e16 = getenv("ACOSS_KEYS16");
-    c->keys16 = !(e16 && strcmp(e16, "0") == 0);
+    // (the Python engine's parser: "0", "false", "no" and the empty string switch off)
+    auto env_off = [](const char *name) {
+        const char *e = getenv(name);
+        return e && (e[0] == 0 || strcmp(e, "0") == 0 || strcmp(e, "false") == 0 || strcmp(e, "no") == 0);
+    };
+    c->force_f64 = env_off("ACOSS_PLANAR32");
+    c->keys16 = !env_off("ACOSS_KEYS16");
     if (c->f32_ok) c->norms_scaled.assign(norms_scaled, norms_scaled + c->n_frames);
     *out = c;
     return ACOSS_OK;
@@ -294,11 +288,19 @@ size_t acoss_serra09_scratch_bytes(const acoss_corpus *c, const int32_t *pairs, 
     if (!c || !pairs || K < 0 || win < 1) return 0;
     std::vector<BatchPlan> plan;
     if (plan_batches(c, pairs, K, win, batch_pairs, plan) != ACOSS_OK) return 0;
+    // sized from the cells the batches really hold (acoss_plan_pairs, as acoss_serra09_scores will plan them) -- every pair at its
+    // batch's largest shape would ask for three to four times the budget on length-skewed corpora
     size_t need = 256;
+    std::vector<int32_t> bp;
+    std::vector<acoss_pair_desc> hd;
     for (const BatchPlan &b : plan) {
-        int64_t csm, crp;
-        batch_elems(b, win, csm, crp);
-        need = std::max(need, carve(c, b.cls, (int)b.idx.size(), b.max_nx, b.max_ny, win, csm, crp).total);
+        const int B = (int)b.idx.size();
+        bp.resize(2 * (size_t)B);
+        hd.resize((size_t)B);
+        for (int t = 0; t < B; t++) { bp[2 * (size_t)t] = pairs[2 * b.idx[(size_t)t]]; bp[2 * (size_t)t + 1] = pairs[2 * b.idx[(size_t)t] + 1]; }
+        int64_t csm = 0, crp = 0;
+        if (acoss_plan_pairs(c->frame_off.data(), c->n_songs, bp.data(), B, win, pitch_of(b.cls), hd.data(), &csm, &crp) != ACOSS_OK) return 0;
+        need = std::max(need, carve(c, b.cls, B, b.max_nx, b.max_ny, win, csm, crp).total);
     }
     return need;
 }

@@ -65,7 +65,6 @@ inline size_t r16_work_bytes(int K, int max_m, int max_n)
     b += r16_align((size_t)K * ldm * sizeof(int)) + r16_align((size_t)K * ldn * sizeof(int));
     b += r16_align((size_t)K * sizeof(int)) + r16_align((size_t)K);
     b += r16_align((size_t)r16_tiles(K, max_m, max_n) * sizeof(int));
-    b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * sizeof(int));
     b += r16_align((size_t)r16_item_cap(K, max_m, max_n) * R16_ITEM_BYTES);
     return b + 256;
 }

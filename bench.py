@@ -1022,10 +1022,9 @@ def main():
                      "for the cells in reach of the error band in r16_exact_tiles_kernel)")
             kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_rows32_kernel<12, 1>"
         elif args.path == "fast32":
-            form = "rows32_kernel<12,0>" if os.environ.get("ACOSS_STRIP32_FORM", "r")[0] != "c" else "strip32_kernel<12>"
-            kname = ("crp_%s (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
-                     "refinement in select_fix_side_kernel)" % form)
-            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, ("crp_rows32_kernel<12, 0>" if form.startswith("rows") else "crp_strip32_kernel<12, 0>")
+            kname = ("crp_rows32_kernel<12,0> (CRPUtils.py:67 + :24 fused, f32 MFMA, float32 keys out: 4 B / cell; exact f64 "
+                     "refinement in select_fix_side_kernel)")
+            kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_rows32_kernel<12, 0>"
         elif args.path == "fast":
             kname = "crp_strip_kernel<12,9,planar> (CRPUtils.py:67 + :24 fused, f64 MFMA, key high words out: 4 B / cell)"
             kms, kwork, key = stage_ms["crp"], runner.crp_bytes, "crp_strip_kernel<12, 9, false, 0, false, true>"

@@ -295,13 +295,18 @@ int acoss_mask_bits_planar32_batch(const uint32_t *keys, const float *band, cons
  * monotone map; same element indexing as the uint32 matrix (element = 2 bytes).  Behind the last key of a row the kernel writes
  * 0xFFFF up to the next multiple of 16 columns (as far as crp_pitch has room: acoss_plan_pairs with pitch_align a multiple of
  * 16 always has): the row selection reads 16 keys per lane and takes such rows without any tail handling; a plane whose pitch
- * is tighter is still selected correctly (the kernel masks the tail itself then).
+ * is tighter is still selected correctly (the kernel masks the tail itself then).  A `keys16` plane handed to
+ * acoss_mask_bits_keys16_batch MUST come from acoss_crp_keys16_batch with the same descriptors (or carry that padding): the
+ * wave-per-row kernels trust it wherever the pitch has room for it; the radix selection masks every tail itself.
  * acoss_mask_bits_keys16_batch selects on those keys; where the winner's error band can reach another key it recomputes
  * the float32 values of the few cells involved from xp / f32 / n32 (the operands acoss_crp_keys16_batch was given, same
  * descriptors) with the strip kernel's arithmetic, and what float32 cannot decide is finished exactly in float64 from
  * feats / norms as in acoss_mask_bits_planar32_batch.  Masks identical to acoss_mask_bits_batch on the float64 sums.
- * CRPUtils.py:67-84 + :24-45 + :169-219; d in {12, 13}, win == 9, matrices up to 1024 x 1024; work / bits sizes as for
- * acoss_mask_bits_batch.  (mutual == 2 / 3 launch the row / the column selection kernel alone and leave `bits` untouched:
+ * Round 5: the selection itself is a radix selection with the keys in registers (csrc/radix16_kernels.hip; ACOSS_RADIX16, default on)
+ * that settles 96 % of the rows and columns on the keys alone and the rest by exact float64 values of the two or three cells in
+ * reach; the recompute tiers above run only for the pairs it hands back (exact ties) and with ACOSS_RADIX16=0.
+ * CRPUtils.py:67-84 + :24-45 + :169-219; d in {12, 13}, win == 9, matrices up to 2048 x 2048 (beyond 1024: see
+ * acoss_mask_bits_keys16_unresolved below); work / bits sizes as for acoss_mask_bits_batch.  (mutual == 2 / 3 launch the row / the column selection kernel alone and leave `bits` untouched:
  * measurement hooks for bench.py's per-kernel rooflines.) */
 int acoss_crp_keys16_batch(const float *xp, const float *feats, const float *norms, int d, const acoss_pair_desc *descs,
                            int K, int win, int max_nx, int max_ny, const uint32_t *koff, uint16_t *out, void *stream);

@@ -111,6 +111,28 @@ def test_scorer_long_songs_with_exact_ties_come_round_again(lib, orc):
                 os.environ[k] = v
 
 
+def test_scorer_switches_on_fresh_handles(lib, orc):
+    """ACOSS_KEYS16 / ACOSS_PLANAR32 are read when a corpus handle is made ("0", "false", "no", "" switch off, as in the Python
+    engine): 32-bit keys and the all-float64 keys give the default's scores, which are the oracle's."""
+    from acoss_amd import synth
+    ch = synth.make_corpus(5, 2, seed=41, lengths=lambda r: int(r.integers(80, 700)))
+    pairs = synth.all_pairs(ch.n_songs).astype(np.int32)
+    q0, d0, _ = _scores(lib, ch.feats, ch.frame_off, ch.gchroma, pairs, want=3)
+    qo, do, _ = orc.serra09_pairs(ch.feats, ch.frame_off, ch.gchroma, pairs, nthreads=min(os.cpu_count() or 1, 16))
+    assert np.array_equal(q0, qo) and np.array_equal(d0, do)
+    for name, value in (("ACOSS_KEYS16", "0"), ("ACOSS_KEYS16", "false"), ("ACOSS_PLANAR32", "0"), ("ACOSS_PLANAR32", "no"), ("ACOSS_RADIX16", "")):
+        old = os.environ.get(name)
+        os.environ[name] = value
+        try:
+            q, d, _ = _scores(lib, ch.feats, ch.frame_off, ch.gchroma, pairs, want=3)
+        finally:
+            if old is None:
+                os.environ.pop(name, None)
+            else:
+                os.environ[name] = old
+        assert np.array_equal(q, q0) and np.array_equal(d, d0), (name, value)
+
+
 def test_scorer_other_widths_windows_and_errors(lib, orc):
     """20-dimensional features and a window of 5 have no fused kernel: one kernel per function, all three recurrences
     (the advisor's case: a silent zero for swc there).  Bad indices and short songs are errors, not zeros."""
