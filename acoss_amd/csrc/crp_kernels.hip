@@ -226,7 +226,7 @@ __global__ __launch_bounds__(GM_THREADS) void csm_gemm_kernel(const double *__re
     const int tiles = tiles_m * tiles_n;
     const int p = blockIdx.x / tiles, t = blockIdx.x % tiles;
     const acoss_pair_desc ds = descs[p];
-    const int i0 = (t / tiles_n) * GM_T, j0 = (t % tiles_n) * GM_T;
+    const int i0 = (t / tiles_n) * GM_T, j0 = (t % tiles_n) * GM_TJ;
     if (i0 >= ds.nx || j0 >= ds.ny) return;
     gemm_nt_tile_f64(
         sm, d,
@@ -964,7 +964,7 @@ static int launch_csm(const T *feats, const T *norms, int d, const acoss_pair_de
     }
     if constexpr (sizeof(T) == 8) {
         if (d >= 32) {        // wide float64 features: matrix cores
-            const int tm = ceil_div(max_nx, GM_T), tn = ceil_div(max_ny, GM_T);
+            const int tm = ceil_div(max_nx, GM_T), tn = ceil_div(max_ny, GM_TJ);
             const int64_t blocks = (int64_t)K * tm * tn;
             if (blocks > 0x7fffffffLL) { set_error("csm_batch: batch too large for one launch"); return ACOSS_ENOTSUP; }
             hipLaunchKernelGGL(csm_gemm_kernel, dim3((unsigned)blocks), dim3(GM_THREADS), 0, st, feats, norms, d, descs, tm, tn, csm);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(GM_THREADS) void ftm2d_gram_kernel(const double *__
                                                                 int n, double *__restrict__ out)
 {
     __shared__ GemmSmem sm;
-    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
+    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_TJ;
     gemm_nt_tile_f64_rows(
         sm, FT_DIM, S + (int64_t)i0 * FT_DIM, FT_DIM, n - i0, S + (int64_t)j0 * FT_DIM, FT_DIM, n - j0,
         [&](const int i, const int j, const double v) {
@@ -306,8 +306,7 @@ int acoss_ftm2d_gram(const double *shingles, int n, double *sims, void *stream)
     double *norms = nullptr;
     if (hipMalloc((void **)&norms, sizeof(double) * (size_t)n) != hipSuccess) { set_error("ftm2d_gram: device allocation failed"); return ACOSS_ENOMEM; }
     hipLaunchKernelGGL(ftm2d_norms_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, shingles, n, norms);
-    const unsigned t = (unsigned)ceil_div(n, GM_T);
-    hipLaunchKernelGGL(ftm2d_gram_kernel, dim3(t, t), dim3(GM_THREADS), 0, st, shingles, norms, n, sims);
+    hipLaunchKernelGGL(ftm2d_gram_kernel, dim3((unsigned)ceil_div(n, GM_TJ), (unsigned)ceil_div(n, GM_T)), dim3(GM_THREADS), 0, st, shingles, norms, n, sims);
     const int rc = launch_check("ftm2d_gram_kernel");
     (void)hipStreamSynchronize(st);
     (void)hipFree(norms);

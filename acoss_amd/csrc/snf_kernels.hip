@@ -215,7 +215,7 @@ __global__ __launch_bounds__(GM_THREADS) void snf_gemm_nt_kernel(const double *_
     __shared__ GemmSmem sm;
     const SnfPair pr = pairs[blockIdx.z];
     const int L = pr.L;
-    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_T;
+    const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_TJ;
     if (i0 >= (rows_m ? pr.M : L) || j0 >= L) return;
     const double *Xp = X + pr.w_off, *Yp = Y + pr.w_off;
     double *Cp = C + pr.w_off;
@@ -307,7 +307,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
     int rc = ACOSS_OK;
     if (hipMemcpyAsync(d_tab, tab, sizeof(SnfPair) * (size_t)K, hipMemcpyHostToDevice, st) != hipSuccess) rc = ACOSS_EIO;
     const dim3 g_el((unsigned)ceil_div(maxL, 256), (unsigned)maxL, (unsigned)K), g_row((unsigned)ceil_div(maxL, 4), (unsigned)K);
-    const dim3 g_mm((unsigned)ceil_div(maxL, GM_T), (unsigned)ceil_div(maxL, GM_T), (unsigned)K);
+    const dim3 g_mm((unsigned)ceil_div(maxL, GM_TJ), (unsigned)ceil_div(maxL, GM_T), (unsigned)K);
     for (int f = 0; f < n_feat && rc == ACOSS_OK; f++) {
         const SnfBlocks b{feats[f].ssma, feats[f].ssmb, feats[f].csm, feats[f].da, feats[f].db, feats[f].dc, feats[f].win};
         if (!b.ssma || !b.ssmb || !b.csm || !b.da || !b.db || !b.dc) { set_error("snf_cross_batch: feature %d has a null pointer", f); rc = ACOSS_EINVAL; break; }
