@@ -437,12 +437,12 @@ __global__ __launch_bounds__(256) void k16_koff_pair_kernel(const float *__restr
                                                             int win, uint32_t *__restrict__ koff)
 {
     __shared__ float mean[2][16];
-    __shared__ float cn[2][1040 + 16];             // centred squared norms of the x and y frames
+    __shared__ float cn[2][2064 + 16];             // centred squared norms of the x and y frames
     __shared__ unsigned wmax[4];                   // [song] centred, [2 + song] raw: window-sum maxima as float bit patterns (>= 0)
     const int p = blockIdx.x;
     const acoss_pair_desc ds = descs[p];
     const int tid = threadIdx.x;
-    if (ds.nx > 1040 || ds.ny > 1040) { if (tid == 0) koff[p] = 0u; return; }      // (block-uniform; the 16-bit path stops at 1032 frames)
+    if (ds.nx > 2064 || ds.ny > 2064) { if (tid == 0) koff[p] = 0u; return; }      // (block-uniform; the 16-bit path stops at 2056 frames)
     if (tid < 32) mean[tid >> 4][tid & 15] = 0.0f;
     if (tid < 4) wmax[tid] = 0u;
     __syncthreads();

@@ -479,9 +479,11 @@ def radix16_stage(what, keys16, band, koff, corpus, batch, kappa, bits, rwork, m
 
 
 def keys16_supported(corpus, batch):
-    """float64 or float32 chroma / MFCC-sized features, the reference's window, matrices up to 1024 x 1024."""
-    return (corpus.d in (12, 13) and batch.win == 9 and batch.max_nx - batch.win + 1 <= 1024
-            and batch.max_ny - batch.win + 1 <= 1024 and planar32_usable(corpus))
+    """float64 or float32 chroma / MFCC-sized features, the reference's window, matrices up to 2048 x 2048 (beyond 1024 x 1024:
+    the long forms of the radix selection -- ACOSS_RADIX16 on --, whose unresolved pairs the caller redoes)."""
+    side = 2048 if _lib.load().acoss_radix16_enabled() else 1024
+    return (corpus.d in (12, 13) and batch.win == 9 and batch.max_nx - batch.win + 1 <= side
+            and batch.max_ny - batch.win + 1 <= side and planar32_usable(corpus))
 
 
 def packed32(corpus):
@@ -889,6 +891,8 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
     # synchronisation at the end: the host plans and launches batch after batch while the GPU works (every scratch buffer is
     # reused in stream order), instead of waiting for each batch's scores before it plans the next.
     pending = []
+    redo = []
+    long_off = False
 
     def fetch_later(lo_, n_, denom_, got_):
         host = {}
@@ -906,6 +910,11 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             for kind, h in host.items():
                 out[kind][lo_:lo_ + n_] = h.numpy().astype(np.float64) / denom_
     for lo in range(0, K, batch_pairs):
+        if long_off:
+            # (a corpus whose thresholds fall below the keys' seven octaves -- unbounded random walks -- left most pairs of the last
+            #  batch of long songs unresolved: the rest of the call goes without the filter)
+            redo.append(np.arange(lo, K, dtype=np.int64))
+            break
         sel = pairs[lo:lo + batch_pairs]
         batch = PairBatch(corpus.frame_off, sel, m, corpus.device, pitch_align=PLANAR_PITCH_ALIGN)
         if do_oti:
@@ -914,8 +923,9 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
         use32 = planar and (planar32_default() if approx32 is None else bool(approx32)) and planar32_usable(corpus)
         # float32 corpora (the reference's mfcc_htk): the same filter on 16-bit keys with the corpus itself as its operand,
         # refined with the exact float32-input arithmetic (round 4); everything else about the batch as for float64
+        k16_ok = keys16_supported(corpus, batch)
         filter32 = (corpus.dtype == np.float32 and (planar32_default() if approx32 is None else bool(approx32)) and keys16_default()
-                    and not fused_default() and keys16_supported(corpus, batch))
+                    and not fused_default() and k16_ok)
         if filter32:
             planar = use32 = True
         fused = use32 and fused_default() and fused_supported(corpus, batch)
@@ -940,12 +950,19 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
             continue
         if fused:
             bits, _ = mask_bits_fused(corpus, batch, kappa, mutual=True, out=bits_buf)
-        elif use32 and keys16_default() and keys16_supported(corpus, batch):
+        elif use32 and keys16_default() and k16_ok:
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
             koff = keys16_koff_f32(corpus, batch, xp32) if filter32 else keys16_koff(corpus, batch)
             band = keys16_band_f32(corpus, batch) if filter32 else planar32_band(corpus, batch)
             k16 = crp_keys16(corpus, batch, xp32, koff, out=T.view(torch.int16)[:planar_elems(batch) + 64])
             bits, work = mask_bits_keys16(k16, band, koff, xp32, corpus, batch, kappa, mutual=True, out=bits_buf, work=work)
+            if bits_words(batch) == 32:
+                # the long form leaves pairs with exact ties unresolved (one synchronisation per batch of long songs): scored
+                # again below without the filter
+                un = mask_bits_keys16_unresolved(work, batch)
+                if len(un):
+                    redo.append(lo + un.astype(np.int64))
+                long_off = len(un) > batch.K // 4
         elif use32:
             xp32 = pack_x32(corpus, batch, out=_scratch("xp32", int(_lib.load().acoss_xpack_elems(batch.K, batch.max_nx)), torch.float32, corpus.device))
             keys = crp_planar32(corpus, batch, xp32, out=T.view(torch.int32)[:planar_elems(batch)])
@@ -984,6 +1001,11 @@ def serra09_scores_py(corpus, pairs, m=9, kappa=0.095, do_oti=True, want=("qmax"
         if "dmax" in want:
             out["dmax"][lo:lo + len(sel)] = align("dmax", B, mats, boundary=1).cpu().numpy().astype(np.float64) / denom
     flush()
+    if redo:
+        part = np.concatenate(redo)
+        res = serra09_scores_py(corpus, pairs[part], m, kappa, do_oti, want, batch_pairs, False)       # (no filter: float64 keys / the plain chain)
+        for k in want:
+            out[k][part] = res[k]
     return out
 
 

@@ -210,3 +210,21 @@ def test_long_form_lists_the_pairs_it_cannot_express(eng):
     for p in range(batch.K):
         if p not in un:
             assert np.array_equal(eng.unpack_mask_bits(bits, batch, p), _byte_mask(B, batch, p)), p
+
+
+def test_long_float32_corpus_through_the_engine(eng):
+    """13-dimensional float32 features (the reference's mfcc_htk) with songs of 1033 .. 1600 frames through engine.serra09_scores: the
+    long form of the filter on the corpus itself, a periodic song's pairs (exact ties) redone without the filter; every score equals
+    the plain float32-input chain's (approx32=False)."""
+    rng = np.random.default_rng(9)
+    lens = [1033, 1600, 1200, 1100, 700]
+    songs = [(np.cumsum(rng.standard_normal((n, 13)), axis=0) * 0.3 + rng.standard_normal((n, 13))).astype(np.float32) for n in lens]
+    pat = rng.random((7, 13)).astype(np.float32) + 0.1
+    songs.append(np.tile(pat, (200, 1))[:1300])
+    feats = np.concatenate(songs)
+    off = np.cumsum([0] + [len(s) for s in songs]).astype(np.int64)
+    corpus = eng.DeviceCorpus(feats, off)
+    pairs = np.array([(i, j) for i in range(6) for j in range(6) if i != j] + [(5, 5)], dtype=np.int32)
+    want = eng.serra09_scores(corpus, pairs, do_oti=False, approx32=False)
+    got = eng.serra09_scores(corpus, pairs, do_oti=False)
+    assert np.array_equal(got["qmax"], want["qmax"]) and np.array_equal(got["dmax"], want["dmax"])

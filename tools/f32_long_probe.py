@@ -1,0 +1,30 @@
+import sys, os, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from acoss_amd import engine, synth
+rng = np.random.default_rng(1)
+S = 128
+if "hpcp" in sys.argv:          # the config-2 chroma as float32 (bounded, stationary): what essentia HPCP looks like
+    ch = synth.config2(n_songs=S, n_frames=1200)
+    feats, off = ch.feats.astype(np.float32), ch.frame_off
+else:                           # unbounded random walks + noise: thresholds below the keys' seven octaves
+    songs = [(np.cumsum(rng.standard_normal((1200, 13)), axis=0) * 0.3 + rng.standard_normal((1200, 13))).astype(np.float32) for _ in range(S)]
+    feats = np.concatenate(songs); off = (np.arange(S + 1) * 1200).astype(np.int64)
+corpus = engine.DeviceCorpus(feats, off)
+pairs = synth.all_pairs(S)[:4096]
+for name, kw in (("filter (long 16-bit keys)", {}), ("plain float32-input chain", {"approx32": False})):
+    engine.serra09_scores(corpus, pairs[:512], do_oti=False, **kw); torch.cuda.synchronize()
+    t0 = time.perf_counter(); r = engine.serra09_scores(corpus, pairs, do_oti=False, **kw); torch.cuda.synchronize()
+    print("%s: 4096 pairs of 1200-frame float32 songs, qmax + dmax: %.1f ms" % (name, 1e3 * (time.perf_counter() - t0)))
+    if name.startswith("filter"): a = r
+print("identical:", np.array_equal(a["qmax"], r["qmax"]) and np.array_equal(a["dmax"], r["dmax"]))
+batch = engine.PairBatch(corpus.frame_off, pairs[:1024], 9, corpus.device, pitch_align=32)
+xp32 = engine.pack_x32(corpus, batch)
+koff = engine.keys16_koff_f32(corpus, batch, xp32); band = engine.keys16_band_f32(corpus, batch)
+k16 = engine.crp_keys16(corpus, batch, xp32, koff)
+bits, work = engine.mask_bits_keys16(k16, band, koff, xp32, corpus, batch, 0.095)
+un = engine.mask_bits_keys16_unresolved(work, batch)
+import ctypes
+st = (ctypes.c_int * 20)()
+engine._lib.load().acoss_mask_bits_keys16_stats(engine._ptr(work), batch.K, batch.max_nx, batch.max_ny, 9, st)
+print("unresolved %d of %d pairs; flagged lines %d; reasons %s" % (len(un), batch.K, st[1], list(st[8:18])))
