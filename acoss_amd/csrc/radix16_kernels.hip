@@ -39,6 +39,9 @@ __device__ inline void r16_lds_add(unsigned byte_off, unsigned v)
 #ifndef R16_COL_NT
 #define R16_COL_NT 0
 #endif
+#ifndef R16_HIT_BRANCH
+#define R16_HIT_BRANCH 1
+#endif
 #if R16_COL_NT
 #define R16_COL_LOAD(p) __builtin_nontemporal_load(p)
 #else
@@ -211,25 +214,6 @@ __device__ inline void r16_decode2(R16Lds &sm, int line, int e, bool valid, int 
             if (valid) { w.pair_flag[p] = 1; atomicAdd(&w.counters[1], 1); atomicAdd(&w.counters[B > 0 ? 15 : 16], 1); t1_out[which] = 0; item_out[which] = -1; }
         }
         return;
-    }
-    if ((d2 & 1u) && sm.sweep3 == 0u) {
-        // the item's cells: lane e looks through the hits of the threads e (and e + 16) that hold keys of the line
-        const int lo = (int)((d2 >> 1) & 0x1FFu), hi = (int)((d2 >> 10) & 0x1FFu);
-        R16Item *it = w.items + sm.ditem[line];
-        const unsigned *hcnt = sm.S;
-        auto take = [&](const unsigned rec) {
-            const int x = (int)(rec & 0x1FFu);
-            if (((int)(rec >> R16_LINE_SHIFT) == line) & (x >= lo) & (x <= hi)) {
-                const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
-                if (slot < (unsigned)R16_CAP) it->pos[slot] = (uint16_t)((rec >> 9) & R16_POS_MASK);
-            }
-        };
-#pragma unroll
-        for (int o = e; o < (DIR ? 32 : 16); o += 16) {
-            const int owner = DIR ? (line >> 1) + R16_WORDS * o : 64 * (4 * (line >> 4) + (o & 3)) + (line & 15) + 16 * (o >> 2);
-            const int h = (int)hcnt[owner];
-            for (int q = 0; q < h; q++) take(sm.hist[q * R16_THREADS + owner]);
-        }
     }
 }
 
@@ -411,8 +395,18 @@ __global__ __launch_bounds__(R16_THREADS, NQ == 32 ? 8 : (NQ == 48 ? 6 : 4)) voi
                 const unsigned x = k16_to_u32(k16_from_u32(wv[q]) - bsh);
                 const unsigned xl = x & 0xFFFFu, xh = x >> 16;
                 const unsigned pos = DIR ? (unsigned)(rs + 32 * q) : (unsigned)(8 * (jj + 16 * (q >> 2)) + 2 * (q & 3));
-                if (xl < lim_a) hit((xl | (pos << 9)) + rec_a);
-                if (xh < lim_b) hit((xh | (pos << 9)) + rec_b);
+                // (a real branch around both hit blocks: hipcc predicates them otherwise -- eight vector instructions and two LDS
+                //  writes per dword with all lanes off; some lane of the wave hits in 0.63 of the dwords)
+                const bool ha = xl < lim_a, hb = xh < lim_b;
+#if R16_HIT_BRANCH
+                if (__ballot(ha | hb) != 0ull) {
+                    if (ha) hit((xl | (pos << 9)) + rec_a);
+                    if (hb) hit((xh | (pos << 9)) + rec_b);
+                }
+#else
+                if (ha) hit((xl | (pos << 9)) + rec_a);
+                if (hb) hit((xh | (pos << 9)) + rec_b);
+#endif
             };
             if (q_end == NQ) {
 #pragma unroll
@@ -441,6 +435,25 @@ __global__ __launch_bounds__(R16_THREADS, NQ == 32 ? 8 : (NQ == 48 ? 6 : 4)) voi
                              pair_band, w, t1_out, item_out, dbg);
             lds_barrier();
             if (t == 0) w.tile_used[item0 / R16_TILE_ITEMS + lb] = (int)min(sm.item_n, (unsigned)R16_TILE_ITEMS);
+        }
+        // ---- the items' cells: every thread looks through its OWN hits (one on average) for those of a line with an item whose x lies in
+        // the item's reach -- all 512 threads at once; sixteen lanes per line walking the slots of the 16 or 32 threads that own
+        // the line's keys took 0.2-0.4 ms of each kernel (a block waits for its slowest wave)
+        if (sm.sweep3 == 0u) {
+            const unsigned kept = sm.S[t];
+            const unsigned slotbase = r16_lds_off(sm.hist) + 4u * (unsigned)t;
+            for (unsigned q = 0; q < (unsigned)R16_SLOTS; q++) {
+                if (__ballot(q < kept) == 0) break;
+                if (q < kept) {
+                    const unsigned rec = *(const r16_lds_word *)(uintptr_t)(slotbase + q * (4u * R16_THREADS));
+                    const unsigned line = rec >> R16_LINE_SHIFT, d = sm.dec[line];
+                    const unsigned x = rec & 0x1FFu, lo = (d >> 1) & 0x1FFu, hi = (d >> 10) & 0x1FFu;
+                    if (((d & 0x80000001u) == 0x80000001u) & (x >= lo) & (x <= hi)) {
+                        const unsigned slot = atomicAdd(&sm.rcnt[line], 1u);
+                        if (slot < (unsigned)R16_CAP) (w.items + sm.ditem[line])->pos[slot] = (uint16_t)((rec >> 9) & R16_POS_MASK);
+                    }
+                }
+            }
         }
         // ---- sweep 3, only in a block where some thread had more hits than slots: the items' cells straight from the registers
         if (sm.sweep3 != 0u) {

@@ -5,13 +5,16 @@ import numpy as np
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from acoss_amd import engine, synth
-ch = synth.make_corpus(4, 4, n_frames=1000, seed=20260)
+odd = "odd" in sys.argv          # songs of 1000 and 999 frames alternate: M + N is odd for half of the pairs
+lens = iter([1000, 999] * 8) if odd else None
+ch = synth.make_corpus(4, 4, seed=20260, lengths=(lambda r: next(lens))) if odd else synth.make_corpus(4, 4, n_frames=1000, seed=20260)
 rng = np.random.default_rng(0)
 chroma = engine.DeviceCorpus(ch.feats, ch.frame_off, gchroma=ch.gchroma)
-ss = [np.cumsum(rng.standard_normal((992, 64)), axis=0) * 0.1 for _ in range(ch.n_songs)]
-ssms = engine.DeviceCorpus(np.concatenate(ss), np.arange(ch.n_songs + 1, dtype=np.int64) * 992)
+nfr = np.diff(ch.frame_off) - 8
+ss = [np.cumsum(rng.standard_normal((int(n), 64)), axis=0) * 0.1 for n in nfr]
+ssms = engine.DeviceCorpus(np.concatenate(ss), np.concatenate([[0], np.cumsum(nfr)]).astype(np.int64))
 allp = synth.all_pairs(ch.n_songs)
-K = int(sys.argv[1]) if len(sys.argv) > 1 else 32
+K = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 32
 pairs = allp[np.arange(K) % len(allp)]
 engine.early_snf_scores(chroma, ssms, pairs[:4])
 torch.cuda.synchronize()
