@@ -4,23 +4,25 @@
 // Why: the wave-per-row kernels of keys16_kernels.hip spend most of their instructions per ROW, not per key -- histogram scan
 // and decode across the lanes, the rank among the winner's bin, the decision, the mask bits: 215 vector + 120 scalar
 // instructions for 16 keys per lane, of which the binning is 48 -- and the column form pays a transposition through LDS on top.
-// Here a block takes a TILE of 64 columns (32 rows) of one pair, every thread keeps its share of the tile's keys in registers
-// (32 dwords) and the block finds all 64 (32) thresholds together:
-//   pass 1   every key adds 1 to the 256-bin histogram of its column (row) over the key's HIGH byte -- LDS atomics, no value
-//            returned; in the column kernel a lane owns a column pair, so the 32 lanes of an LDS lane group never meet in a bank;
-//   decode 1 one lane per column walks its 256 counts: bin B of the k-th smallest, cb = keys below that bin;
-//   pass 2   every key is compared with its column's window [256 B - 1, 256 B + 256] (one packed subtraction, two compares);
-//            the few keys inside (7.7 on average at 1000 frames) go to the column's list with their row;
-//   decode 2 sixteen lanes per column rank the list: the k-th smallest key th, how many keys are <= th, whether a key in the
-//            reach of th's float32 error band lies above it.  If exactly k keys are <= th and none above is in reach, the
-//            column's selection is `key <= th` (96 % of the benchmark's rows and columns); otherwise the cells in reach become a
-//            work item and exact float64 values decide among them (r16_exact_kernel) -- the same set fix_row_band_range
-//            (planar_select.h) selects, so the masks are the float64 path's bit for bit.
+// Here a block takes a TILE of 32 lines (rows or columns) x all positions of one pair, sixteen threads per line; every thread keeps
+// its share of the tile's keys in registers (32 dwords; 48 / 64 for sides up to 1536 / 2048: NQ) and the block finds all 32
+// thresholds together:
+//   pass 1   every key adds 1 to the 256-bin histogram of its line over the key's HIGH byte -- LDS atomics, no value returned; in
+//            the column kernel a lane owns a column pair, so the 32 lanes of an LDS lane group never meet in a bank;
+//   decode 1 one lane per line walks its 256 counts: bin B of the k-th smallest, cb = keys below that bin;
+//   pass 2   every key is compared with its line's window [256 B - 1, 256 B + 256] (one packed subtraction, two compares, one
+//            wave-uniform branch); the few keys inside (7.7 on average at 1000 frames) are kept in the thread's own LDS slots and
+//            counted (by sixteens, by key) after the sweep;
+//   decode 2 sixteen lanes per line find the k-th smallest key th, how many keys are <= th, whether a key in the reach of th's
+//            float32 error band lies beside it.  If exactly k keys are <= th and none above is in reach, the line's selection is
+//            `key <= th` (96 % of the benchmark's rows and columns); otherwise the cells in reach become a work item (every thread
+//            contributes the ones among its own hits) and exact float64 values decide among them (r16_exact_tiles_kernel) -- the
+//            same set fix_row_band_range (planar_select.h) selects, so the masks are the float64 path's bit for bit.
 // The row kernel does the same per row (a wave owns four rows: coalesced 1 KB loads, bank conflicts in pass 1 accepted) and,
 // with both thresholds known, writes the mutual mask's base bits `key < min(t1_row, t1_col)` straight from its registers, one
 // byte per lane and 8 columns; r16_apply_kernel adds the few cells the work items select.  No per-row cross-lane scan, no
-// transposition, no bit planes, no combine kernel.  Per key: ~14 vector instructions in the column kernel, ~19 in the row
-// kernel (the wave-per-row kernels: 14 + 18 lane operations per cell) -- both kernels wait for HBM.
+// transposition, no bit planes, no combine kernel.  Per key ~14 vector + 8 scalar instructions in either kernel; PMC: the vector
+// ALUs are active 0.91 / 0.81 of the cycles (columns / rows) -- bound by instruction issue.
 #include "radix16.h"
 
 #include <stdlib.h>
