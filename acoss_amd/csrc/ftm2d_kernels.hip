@@ -208,6 +208,26 @@ __global__ __launch_bounds__(GM_THREADS) void ftm2d_gram_kernel(const double *__
         });
 }
 
+#ifndef GM_DMA
+#define GM_DMA 1
+#endif
+// the same through gemm_nt_tile_f64_dma (gemm_f64.h: operands into LDS by the DMA path, 128 x 128 tiles): FT_DIM is even, the shingle
+// matrix 16-byte aligned
+__global__ __launch_bounds__(GD_THREADS) void ftm2d_gram_dma_kernel(const double *__restrict__ S, const double *__restrict__ norms,
+                                                                    int n, double *__restrict__ out)
+{
+    __shared__ GemmDmaSmem sm;
+    const int i0 = blockIdx.y * GD_T, j0 = blockIdx.x * GD_T;
+    gemm_nt_tile_f64_dma(
+        sm, FT_DIM, S + (int64_t)i0 * FT_DIM, FT_DIM, n - i0, S + (int64_t)j0 * FT_DIM, FT_DIM, n - j0,
+        [&](const int i, const int j, const double v) {
+            if (i0 + i < n && j0 + j < n) {
+                const double d = fmax(fma(-2.0, v, norms[i0 + i] + norms[j0 + j]), 0.0);
+                out[(int64_t)(i0 + i) * n + j0 + j] = exp(-d);
+            }
+        });
+}
+
 }  // namespace acoss
 
 using namespace acoss;
@@ -306,6 +326,9 @@ int acoss_ftm2d_gram(const double *shingles, int n, double *sims, void *stream)
     double *norms = nullptr;
     if (hipMalloc((void **)&norms, sizeof(double) * (size_t)n) != hipSuccess) { set_error("ftm2d_gram: device allocation failed"); return ACOSS_ENOMEM; }
     hipLaunchKernelGGL(ftm2d_norms_kernel, dim3((unsigned)ceil_div(n, 4)), dim3(256), 0, st, shingles, n, norms);
+    if (GM_DMA && (FT_DIM & 1) == 0 && ((uintptr_t)shingles & 15) == 0)
+        hipLaunchKernelGGL(ftm2d_gram_dma_kernel, dim3((unsigned)ceil_div(n, GD_T), (unsigned)ceil_div(n, GD_T)), dim3(GD_THREADS), 0, st, shingles, norms, n, sims);
+    else
     hipLaunchKernelGGL(ftm2d_gram_kernel, dim3((unsigned)ceil_div(n, GM_TJ), (unsigned)ceil_div(n, GM_T)), dim3(GM_THREADS), 0, st, shingles, norms, n, sims);
     const int rc = launch_check("ftm2d_gram_kernel");
     (void)hipStreamSynchronize(st);

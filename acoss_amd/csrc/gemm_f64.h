@@ -192,3 +192,91 @@ __device__ inline void gemm_nt_tile_f64_rows(GemmSmem &sm, int kdim, const doubl
 }
 
 }  // namespace acoss
+
+// ---- the same product with its operands brought into LDS by the DMA path (global_load_lds_dwordx4: no staging registers, no ds_write)
+// into TWO images, one barrier per chunk (round 5; snf_kernels.hip and ftm2d_kernels.hip use it where the operands' leading
+// dimensions are even: -DGM_DMA=0 switches it off).  Per product of 32 pairs of 1984^3: 8.19 ms against 8.75 for the register-staged 128 x 64
+// form above (0.83 of the f64 matrix peak; operands a pair of steps ahead in a second register set: no change).  128 x 128 tile, 1024 threads = sixteen
+// waves of 32 x 32, one block per CU (133 KB of LDS).  A wave instruction of the DMA path writes 1 KB = four rows x 32 doubles
+// contiguously; the image keeps those groups 1040 bytes apart and puts rows r, r + 32, r + 64, r + 96 into one group, so the sixteen
+// rows of an operand read (r .. r + 15: sixteen different groups) meet in different banks with plain immediate offsets for the steps.
+namespace acoss {
+
+constexpr int GD_T = 128, GD_KC = 32, GD_THREADS = 1024, GD_GROUP = 1024 + 16, GD_OPB = 32 * GD_GROUP;
+
+struct GemmDmaSmem {
+    __attribute__((aligned(16))) char img[2][2][GD_OPB];          // [buffer][A / B][32 groups]
+};
+
+static __device__ __attribute__((aligned(16))) double gd_zero[2] = {0.0, 0.0};       // what lanes behind the end of the contraction axis load
+
+// operands as gemm_nt_tile_f64_rows's; needs lda, ldb, kdim even and 16-byte aligned bases (the caller checks)
+template <typename Store>
+__device__ inline void gemm_nt_tile_f64_dma(GemmDmaSmem &sm, int kdim, const double *__restrict__ A, int lda, int rowsA,
+                                            const double *__restrict__ B, int ldb, int rowsB, Store store)
+{
+    typedef const __attribute__((address_space(1))) void *gptr_t;
+    typedef __attribute__((address_space(3))) void *lptr_t;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int wi = (wave >> 2) * 32, wj = (wave & 3) * 32;
+    v4f64_g acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++) acc[a][b] = (v4f64_g){0.0, 0.0, 0.0, 0.0};
+    // wave w brings groups w and w + 16 of either operand: lane (s = lane >> 4, piece = lane & 15) -> row group + 32 s, doubles 2 piece, + 1
+    const int piece = lane & 15, slot = lane >> 4;
+    const double *srcA[2], *srcB[2];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int row = wave + 16 * q + 32 * slot;
+        srcA[q] = A + (int64_t)min(row, rowsA - 1) * lda + 2 * piece;
+        srcB[q] = B + (int64_t)min(row, rowsB - 1) * ldb + 2 * piece;
+    }
+    auto dma = [&](const int buf, const int k0) {
+        const bool in = k0 + 2 * piece < kdim;
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            __builtin_amdgcn_global_load_lds((gptr_t)(in ? srcA[q] + k0 : gd_zero), (lptr_t)(sm.img[buf][0] + (wave + 16 * q) * GD_GROUP), 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((gptr_t)(in ? srcB[q] + k0 : gd_zero), (lptr_t)(sm.img[buf][1] + (wave + 16 * q) * GD_GROUP), 16, 0, 0);
+        }
+    };
+    const bool live = wi < rowsA && wj < rowsB;
+    const int offA = lr * GD_GROUP + (wave >> 2) * 256 + lk * 8, offB = lr * GD_GROUP + (wave & 3) * 256 + lk * 8;
+    dma(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int cur = 0;
+    for (int k0 = 0; k0 < kdim; k0 += GD_KC) {
+        if (k0 + GD_KC < kdim) dma(cur ^ 1, k0 + GD_KC);
+        if (live) {
+            const char *ia = sm.img[cur][0] + offA, *ib = sm.img[cur][1] + offB;
+#pragma unroll
+            for (int kk = 0; kk < GD_KC; kk += 4) {
+                double a[2], b[2];
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    a[t] = *reinterpret_cast<const double *>(ia + 16 * t * GD_GROUP + kk * 8);
+                    b[t] = *reinterpret_cast<const double *>(ib + 16 * t * GD_GROUP + kk * 8);
+                }
+#pragma unroll
+                for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+                    for (int tb = 0; tb < 2; tb++)
+                        acc[ta][tb] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[ta], b[tb], acc[ta][tb], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+        for (int tb = 0; tb < 2; tb++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) store(wi + 16 * ta + lk + 4 * r, wj + 16 * tb + lr, acc[ta][tb][r]);
+}
+
+}  // namespace acoss

@@ -18,9 +18,11 @@
 namespace acoss {
 
 struct SnfPair {            // one per pair, device table
-    int64_t w_off;          // element offset of the pair's L x L matrices inside every matrix buffer
+    int64_t w_off;          // element offset of the pair's L x L matrices inside every matrix buffer: rows ld apart
     int64_t md_off;         // offset of its 2 L local-scale means
+    int64_t c_off;          // its offset in a buffer of packed L x L matrices (debug outputs)
     int M, N, k1, k2, K, L;
+    int ld;                 // L rounded up to even (16-byte rows: the DMA form of the products); the pad column holds zeros
 };
 
 struct SnfBlocks {          // the three distance matrices of one feature and their pair layouts
@@ -117,7 +119,8 @@ __global__ __launch_bounds__(256) void snf_wfill_kernel(SnfBlocks f, const SnfPa
     const int p = blockIdx.z;
     const SnfPair pr = pairs[p];
     const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (r >= pr.L || c >= pr.L) return;
+    if (r >= pr.L || c >= pr.ld) return;
+    if (c >= pr.L) { W[pr.w_off + (int64_t)r * pr.ld + c] = 0.0; return; }      // the pad column
     const int M = pr.M, L = pr.L;
     const double *m = md + pr.md_off;
     const double d = snf_block_value(f, p, M, r, c);
@@ -129,7 +132,7 @@ __global__ __launch_bounds__(256) void snf_wfill_kernel(SnfBlocks f, const SnfPa
     const double eps = (mr + mc + d) / 3.0;
     double den = 2.0 * ((Mu * eps) * (Mu * eps));
     if (self && den == 0.0) den = 1.0;                                  // :69-70 (get_W only)
-    W[pr.w_off + (int64_t)r * L + c] = exp(-(d * d) / den);
+    W[pr.w_off + (int64_t)r * pr.ld + c] = exp(-(d * d) / den);
 }
 
 // row sums without the diagonal (get_P :147-149, snf_ws :258-260), one wave per row, fixed order
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(256) void snf_rowsum_kernel(const double *__restric
     const SnfPair pr = pairs[p];
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= pr.L) return;
-    const double *row = X + pr.w_off + (int64_t)r * pr.L;
+    const double *row = X + pr.w_off + (int64_t)r * pr.ld;
     double s = 0.0;
     for (int c = lane; c < pr.L; c += 64) s += c == r ? 0.0 : row[c];
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
@@ -154,11 +157,11 @@ __global__ __launch_bounds__(256) void snf_reg_kernel(const double *__restrict__
     const int p = blockIdx.z;
     const SnfPair pr = pairs[p];
     const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (r >= pr.L || c >= pr.L) return;
+    if (r >= pr.L || c >= pr.ld) return;
     double rs = rowsum[pr.md_off / 2 + r];
     if (rs == 0.0) rs = 1.0;
-    const int64_t at = pr.w_off + (int64_t)r * pr.L + c;
-    P[at] = r == c ? 0.5 : 0.5 * X[at] / rs;
+    const int64_t at = pr.w_off + (int64_t)r * pr.ld + c;
+    P[at] = c >= pr.L ? 0.0 : (r == c ? 0.5 : 0.5 * X[at] / rs);
 }
 
 // S: the K largest entries of every row of W, divided by their sum (:170-180); ties cut lowest column first
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(256) void snf_topk_kernel(const double *__restrict_
     const SnfPair pr = pairs[p];
     const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (r >= pr.L) return;
-    const double *row = W + pr.w_off + (int64_t)r * pr.L;
+    const double *row = W + pr.w_off + (int64_t)r * pr.ld;
     double x[32];
     uint64_t key[32];
     int idx[32];
@@ -190,10 +193,19 @@ __global__ __launch_bounds__(256) void snf_topk_kernel(const double *__restrict_
     for (int d = 32; d > 0; d >>= 1) s += __shfl_down(s, d, 64);
     s = __shfl(s, 0, 64);
     if (s == 0.0) s = 1.0;
-    double *out = S + pr.w_off + (int64_t)r * pr.L;
+    double *out = S + pr.w_off + (int64_t)r * pr.ld;
 #pragma unroll
     for (int e = 0; e < 32; e++)
-        if (idx[e] < pr.L) out[idx[e]] = on[e] ? x[e] / s : 0.0;
+        if (idx[e] < pr.ld) out[idx[e]] = (idx[e] < pr.L && on[e]) ? x[e] / s : 0.0;
+}
+
+// the pair's L x L matrix out of its padded rows, into a buffer of packed matrices (debug outputs)
+__global__ __launch_bounds__(256) void snf_unpad_kernel(const double *__restrict__ src, const SnfPair *__restrict__ pairs, double *__restrict__ dst)
+{
+    const SnfPair pr = pairs[blockIdx.z];
+    const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (r >= pr.L || c >= pr.L) return;
+    dst[pr.c_off + (int64_t)r * pr.L + c] = src[pr.w_off + (int64_t)r * pr.ld + c];
 }
 
 // out = mean of n_src matrices (:241-246), used when more than two features are fused
@@ -214,13 +226,36 @@ __global__ __launch_bounds__(GM_THREADS) void snf_gemm_nt_kernel(const double *_
 {
     __shared__ GemmSmem sm;
     const SnfPair pr = pairs[blockIdx.z];
-    const int L = pr.L;
+    const int L = pr.L, ld = pr.ld;
     const int i0 = blockIdx.y * GM_T, j0 = blockIdx.x * GM_TJ;
     if (i0 >= (rows_m ? pr.M : L) || j0 >= L) return;
     const double *Xp = X + pr.w_off, *Yp = Y + pr.w_off;
     double *Cp = C + pr.w_off;
-    gemm_nt_tile_f64_rows(sm, L, Xp + (int64_t)i0 * L, L, L - i0, Yp + (int64_t)j0 * L, L, L - j0,
-                          [&](const int i, const int j, const double v) { if (i0 + i < L && j0 + j < L) Cp[(int64_t)(i0 + i) * L + j0 + j] = v; });
+    // (the contraction runs over ld: the pad column of both operands holds zeros; the result's pad column is written as zero)
+    gemm_nt_tile_f64_rows(sm, ld, Xp + (int64_t)i0 * ld, ld, L - i0, Yp + (int64_t)j0 * ld, ld, L - j0,
+                          [&](const int i, const int j, const double v) {
+                              if (i0 + i < L && j0 + j < ld) Cp[(int64_t)(i0 + i) * ld + j0 + j] = j0 + j < L ? v : 0.0;
+                          });
+}
+
+#ifndef GM_DMA
+#define GM_DMA 1
+#endif
+// the same product through gemm_nt_tile_f64_dma (gemm_f64.h): rows are ld = L rounded up to even doubles apart (16-byte rows)
+__global__ __launch_bounds__(GD_THREADS) void snf_gemm_nt_dma_kernel(const double *__restrict__ X, const double *__restrict__ Y,
+                                                                     const SnfPair *__restrict__ pairs, double *__restrict__ C, int rows_m)
+{
+    __shared__ GemmDmaSmem sm;
+    const SnfPair pr = pairs[blockIdx.z];
+    const int L = pr.L, ld = pr.ld;
+    const int i0 = blockIdx.y * GD_T, j0 = blockIdx.x * GD_T;
+    if (i0 >= (rows_m ? pr.M : L) || j0 >= L) return;
+    const double *Xp = X + pr.w_off, *Yp = Y + pr.w_off;
+    double *Cp = C + pr.w_off;
+    gemm_nt_tile_f64_dma(sm, ld, Xp + (int64_t)i0 * ld, ld, L - i0, Yp + (int64_t)j0 * ld, ld, L - j0,
+                         [&](const int i, const int j, const double v) {
+                             if (i0 + i < L && j0 + j < ld) Cp[(int64_t)(i0 + i) * ld + j0 + j] = j0 + j < L ? v : 0.0;
+                         });
 }
 
 // -(mean_f P_f)[0:M, M:] into the pair's cross-recurrence layout (EarlySNF.py:84-85)
@@ -233,7 +268,7 @@ __global__ __launch_bounds__(256) void snf_cross_kernel(const double *const *__r
     const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (r >= pr.M || c >= pr.N) return;
     double s = 0.0;
-    for (int k = 0; k < n_feat; k++) s += P[k][pr.w_off + (int64_t)r * pr.L + pr.M + c];      // fused_score, :182-189
+    for (int k = 0; k < n_feat; k++) s += P[k][pr.w_off + (int64_t)r * pr.ld + pr.M + c];      // fused_score, :182-189
     out[dout[p].crp_off + (int64_t)r * dout[p].crp_pitch + c] = -(s / (double)n_feat);
 }
 
@@ -247,7 +282,7 @@ extern "C" {
 static int64_t snf_total_elems(const int32_t *M, const int32_t *N, int K)
 {
     int64_t t = 0;
-    for (int p = 0; p < K; p++) { const int64_t L = (int64_t)M[p] + N[p]; t += L * L; }
+    for (int p = 0; p < K; p++) { const int64_t L = (int64_t)M[p] + N[p]; t += L * ((L + 1) & ~(int64_t)1); }      // rows ld apart
     return t;
 }
 
@@ -275,7 +310,7 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
     // per-pair table (EarlySNF.py:51: K = int(kappa (M + N)); SimilarityFusion.py:127-128: k1, k2)
     SnfPair *tab = (SnfPair *)malloc(sizeof(SnfPair) * (size_t)K);
     if (!tab) { set_error("snf_cross_batch: out of host memory"); return ACOSS_ENOMEM; }
-    int64_t woff = 0, mdoff = 0;
+    int64_t woff = 0, mdoff = 0, coff = 0;
     int maxL = 0;
     for (int p = 0; p < K; p++) {
         SnfPair &t = tab[p];
@@ -288,8 +323,10 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
             free(tab);
             return t.L > 2048 ? ACOSS_ENOTSUP : ACOSS_EINVAL;
         }
-        t.w_off = woff; t.md_off = mdoff;
-        woff += (int64_t)t.L * t.L;
+        t.ld = (t.L + 1) & ~1;
+        t.w_off = woff; t.md_off = mdoff; t.c_off = coff;
+        woff += (int64_t)t.L * t.ld;
+        coff += (int64_t)t.L * t.L;
         mdoff += 2 * (int64_t)t.L;
         maxL = t.L > maxL ? t.L : maxL;
     }
@@ -306,15 +343,17 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
     const double **d_ptrs = (const double **)(d_tab + K);
     int rc = ACOSS_OK;
     if (hipMemcpyAsync(d_tab, tab, sizeof(SnfPair) * (size_t)K, hipMemcpyHostToDevice, st) != hipSuccess) rc = ACOSS_EIO;
-    const dim3 g_el((unsigned)ceil_div(maxL, 256), (unsigned)maxL, (unsigned)K), g_row((unsigned)ceil_div(maxL, 4), (unsigned)K);
+    const dim3 g_el((unsigned)ceil_div(maxL + 1, 256), (unsigned)maxL, (unsigned)K), g_row((unsigned)ceil_div(maxL, 4), (unsigned)K);
     const dim3 g_mm((unsigned)ceil_div(maxL, GM_TJ), (unsigned)ceil_div(maxL, GM_T), (unsigned)K);
+    const dim3 g_dma((unsigned)ceil_div(maxL, GD_T), (unsigned)ceil_div(maxL, GD_T), (unsigned)K);
+    const bool use_dma = GM_DMA != 0 && ((uintptr_t)scratch & 15) == 0;          // (every row starts on 16 bytes: ld and every w_off are even)
     for (int f = 0; f < n_feat && rc == ACOSS_OK; f++) {
         const SnfBlocks b{feats[f].ssma, feats[f].ssmb, feats[f].csm, feats[f].da, feats[f].db, feats[f].dc, feats[f].win};
         if (!b.ssma || !b.ssmb || !b.csm || !b.da || !b.db || !b.dc) { set_error("snf_cross_batch: feature %d has a null pointer", f); rc = ACOSS_EINVAL; break; }
         hipLaunchKernelGGL(snf_stats_kernel, dim3((unsigned)ceil_div(2 * maxL, 4), (unsigned)K), dim3(256), 0, st, b, d_tab, 2 * maxL, md);
         hipLaunchKernelGGL(snf_wfill_kernel, g_el, dim3(256), 0, st, b, d_tab, mu, md, Pm[f]);            // W lives in the P buffer
         if ((rc = launch_check("snf affinity kernels")) != ACOSS_OK) break;
-        if (debug_W && hipMemcpyAsync(debug_W + (int64_t)f * tot, Pm[f], sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st) != hipSuccess) rc = ACOSS_EIO;
+        if (debug_W) hipLaunchKernelGGL(snf_unpad_kernel, g_el, dim3(256), 0, st, Pm[f], d_tab, debug_W + (int64_t)f * coff);
         hipLaunchKernelGGL(snf_topk_kernel, g_row, dim3(256), 0, st, Pm[f], d_tab, Sm[f]);
         hipLaunchKernelGGL(snf_rowsum_kernel, g_row, dim3(256), 0, st, Pm[f], d_tab, rowsum);
         hipLaunchKernelGGL(snf_reg_kernel, g_el, dim3(256), 0, st, Pm[f], d_tab, rowsum, Pm[f]);          // P = get_P(W, reg_diag)
@@ -338,11 +377,15 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                 hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n, tot, Xm);
                 src = Xm;
             }
+            if (use_dma) hipLaunchKernelGGL(snf_gemm_nt_dma_kernel, g_dma, dim3(GD_THREADS), 0, st, Sm[i], src, d_tab, Am, 0);
+            else
             hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], src, d_tab, Am, 0);    // A = S . P^T   (:251)
             double *dst = (it == 0) ? Pn[i] : Pm[i];
             // the very last product: only rows 0 .. M - 1 are ever read (by snf_cross_kernel) -- unless the caller wants the whole
             // fused matrix (debug_fused), or further features of this iteration read it (they read the features before them)
             const int rows_m = (it == niters - 1 && i == n_feat - 1 && debug_fused == nullptr) ? 1 : 0;
+            if (use_dma) hipLaunchKernelGGL(snf_gemm_nt_dma_kernel, g_dma, dim3(GD_THREADS), 0, st, Sm[i], Am, d_tab, dst, rows_m);
+            else
             hipLaunchKernelGGL(snf_gemm_nt_kernel, g_mm, dim3(GM_THREADS), 0, st, Sm[i], Am, d_tab, dst, rows_m);       // S . A^T       (:252)
             hipLaunchKernelGGL(snf_rowsum_kernel, g_row, dim3(256), 0, st, dst, d_tab, rowsum);
             hipLaunchKernelGGL(snf_reg_kernel, g_el, dim3(256), 0, st, dst, d_tab, rowsum, dst);          // :254-262
@@ -363,7 +406,8 @@ int acoss_snf_cross_batch(const acoss_snf_feature *feats, int n_feat, int K, con
                                d_ptrs, n_feat, d_tab, dout, cross_out);
             rc = launch_check("snf_cross_kernel");
             if (rc == ACOSS_OK && debug_fused) {
-                hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n_feat, tot, debug_fused);
+                hipLaunchKernelGGL(snf_mean_kernel, dim3((unsigned)ceil_div64(tot, 256)), dim3(256), 0, st, d_ptrs, n_feat, tot, Xm);
+                hipLaunchKernelGGL(snf_unpad_kernel, g_el, dim3(256), 0, st, Xm, d_tab, debug_fused);
                 rc = launch_check("snf_mean_kernel");
             }
         }
