@@ -285,14 +285,26 @@ def song_variation(corpus):
     float32 filter's resolution is measured against when two songs of very different loudness meet (serra09_scores_py)."""
     v = getattr(corpus, "_variation", None)
     if v is None:
-        f = corpus.feats.to(torch.float64)
-        off = corpus.frame_off
-        v = np.zeros(corpus.n_songs)
-        for s_ in range(corpus.n_songs):
-            a, b = int(off[s_]), int(off[s_ + 1])
+        # segmented sums on the device, a few million frames at a time (whole songs), one download at the end
+        off = np.asarray(corpus.frame_off, dtype=np.int64)
+        lens = np.diff(off)
+        parts = []
+        s0 = 0
+        while s0 < corpus.n_songs:
+            s1 = int(np.searchsorted(off, off[s0] + (1 << 21), side="right")) - 1
+            s1 = min(max(s1, s0 + 1), corpus.n_songs)
+            a, b = int(off[s0]), int(off[s1])
+            n = torch.as_tensor(np.maximum(lens[s0:s1], 1), dtype=torch.float64, device=corpus.device)
             if b > a:
-                x = f[a:b]
-                v[s_] = float(((x - x.mean(0, keepdim=True)) ** 2).sum(1).mean().item())
+                x = corpus.feats[a:b].to(torch.float64)
+                seg = torch.repeat_interleave(torch.arange(s1 - s0, device=corpus.device), torch.as_tensor(lens[s0:s1], device=corpus.device))
+                mean = torch.zeros((s1 - s0, x.shape[1]), dtype=torch.float64, device=corpus.device).index_add_(0, seg, x) / n[:, None]
+                sq = ((x - mean[seg]) ** 2).sum(1)
+                parts.append(torch.zeros(s1 - s0, dtype=torch.float64, device=corpus.device).index_add_(0, seg, sq) / n)
+            else:
+                parts.append(torch.zeros(s1 - s0, dtype=torch.float64, device=corpus.device))
+            s0 = s1
+        v = torch.cat(parts).cpu().numpy() if parts else np.zeros(0)
         corpus._variation = v
     return v
 
