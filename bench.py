@@ -13,6 +13,10 @@ the score vectors closes the timed region.
     python bench.py [--gpus N] [--steps K] [--warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Setup, before the W warm-up steps: `--device-warmup-s` seconds (default 0.6) of the same steps, untimed -- the first process on a freshly
+started box otherwise runs its memory-bound selection kernels ~40 % slow for the first 0.2 s, which at W = 3, K = 20 is the whole
+measurement (`config.device_warmup_s`; 0 switches it off).
+
 Without a launcher (`WORLD_SIZE` unset) and N > 1 the parent process starts the N ranks itself, as a child
 torch.distributed.run, before anything touches the GPU.  A `--gpus` that disagrees with the launcher's world size is
 an error.
@@ -25,8 +29,9 @@ chain.  Beside each live block: the same kernel's average in the committed rocpr
 (ACOSS_BENCH_ARENA_GB=<n> scans the windows of an n-GB arena for the fastest one first: rounds 2-3's placement study, opt-in).
 Beside the headline (rank 0, one GPU; `--no-extras` skips them): `roofline_csm_*` = the stand-alone get_csm kernels;
 `cpu_baseline` / `parity` = the CPU oracle's chain on the host cores and whether the GPU scores of the sampled pairs are
-identical (also on N > 1 lines); `keys32_path` / `f64_path` / `fused` = the same steps with 32-bit keys, with every windowed sum
-in float64, with the masks from the fused band kernel (scores must be identical); `plugin` = pairs/s through the one-call C
+identical (also on N > 1 lines); with `--extras-all`: `keys32_path` / `f64_path` / `fused` = the same steps with 32-bit keys, with every
+windowed sum in float64, with the masks from the fused band kernel (scores must be identical); `hpcp_f32` / `smooth` / `frames_1200` = the
+product call on the corpus as float32, on temporally smooth frames, on 1200-frame songs, each checked against the oracle; `plugin` = pairs/s through the one-call C
 scorer; `full_job` = the whole 499 500-pair job through Serra09.all_pairwise + getEvalStatistics with MAP, and the 64-song slice
 against the reference's own scores and statistics ("MAP vs ref" of BASELINE.json:metric); `plugin_similarity` =
 Serra09.similarity as the reference's drivers call it (chroma + MFCC, qmax + dmax each); `scatter_chain` / `scatter_csm` = the
