@@ -1,5 +1,7 @@
+"""float32 corpora with 1200-frame songs through engine.serra09_scores: the long 16-bit-key forms against the plain float32-input chain
+(dev tool, round 5).  usage: python tools/f32_long_probe.py [hpcp]   (hpcp: the config-2 chroma as float32 instead of 13-d random walks)"""
 import sys, os, time
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from acoss_amd import engine, synth
 rng = np.random.default_rng(1)

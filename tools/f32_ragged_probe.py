@@ -1,3 +1,5 @@
+"""Stage times of the 16-bit-key chain on a float32 corpus of 13-d random walks (the MFCC stand-in), ragged or PROBE_FRAMES long, with the radix
+selection on and off, against the plain float32-input chain (dev tool, rounds 4-5).  usage: [PROBE_FRAMES=1000] python tools/f32_ragged_probe.py"""
 import sys, os, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

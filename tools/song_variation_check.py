@@ -1,3 +1,4 @@
+"""engine.song_variation (segmented sums on the device) against numpy per song (dev tool, round 5)."""
 import sys; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from acoss_amd import engine
