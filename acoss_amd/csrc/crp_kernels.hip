@@ -279,16 +279,19 @@ __global__ __launch_bounds__(GM32_THREADS, 2) void csm_gemm32_kernel(const float
         }
         return make_float4(e[0], e[1], e[2], e[3]);
     };
-    gemm_nt_tile_f32(
-        sm, d,
-        [&](const int r, const int k) { return row_quad(ds.x_row0 + i0, ds.nx - i0, r, k, ds.shift); },
-        [&](const int r, const int k) { return row_quad(ds.y_row0 + j0, ds.ny - j0, r, k, 0); },
-        [&](const int i, const int j, const float v) {
-            if (i0 + i < ds.nx && j0 + j < ds.ny) {
-                const float c = fmaf(-2.0f, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
-                out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
-            }
-        });
+    auto store = [&](const int i, const int j, const float v) {
+        if (i0 + i < ds.nx && j0 + j < ds.ny) {
+            const float c = fmaf(-2.0f, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
+            out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
+        }
+    };
+    if (quads)          // (no rotation, whole quads, aligned rows: one pointer per staged quad -- the scattering features' case)
+        gemm_nt_tile_f32_rows(sm, d, feats + (ds.x_row0 + i0) * (int64_t)d, d, ds.nx - i0, feats + (ds.y_row0 + j0) * (int64_t)d, d, ds.ny - j0, store);
+    else
+        gemm_nt_tile_f32(
+            sm, d,
+            [&](const int r, const int k) { return row_quad(ds.x_row0 + i0, ds.nx - i0, r, k, ds.shift); },
+            [&](const int r, const int k) { return row_quad(ds.y_row0 + j0, ds.ny - j0, r, k, 0); }, store);
 }
 
 // ---------------------------------------------------------------------------------------------
