@@ -228,20 +228,23 @@ __global__ __launch_bounds__(GM_THREADS) void csm_gemm_kernel(const double *__re
     const acoss_pair_desc ds = descs[p];
     const int i0 = (t / tiles_n) * GM_T, j0 = (t % tiles_n) * GM_TJ;
     if (i0 >= ds.nx || j0 >= ds.ny) return;
-    gemm_nt_tile_f64(
-        sm, d,
-        [&](const int r, const int k) {
-            int src = k - ds.shift;                    // np.roll(chroma_i, oti) (Serra09.py:167)
-            if (src < 0) src += d;
-            return (i0 + r < ds.nx && k < d) ? feats[(ds.x_row0 + i0 + r) * d + src] : 0.0;
-        },
-        [&](const int r, const int k) { return (j0 + r < ds.ny && k < d) ? feats[(ds.y_row0 + j0 + r) * d + k] : 0.0; },
-        [&](const int i, const int j, const double v) {
-            if (i0 + i < ds.nx && j0 + j < ds.ny) {
-                const double c = fma(-2.0, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
-                out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
-            }
-        });
+    auto store = [&](const int i, const int j, const double v) {
+        if (i0 + i < ds.nx && j0 + j < ds.ny) {
+            const double c = fma(-2.0, v, norms[ds.x_row0 + i0 + i] + norms[ds.y_row0 + j0 + j]);
+            out[ds.csm_off + (int64_t)(i0 + i) * ds.csm_pitch + j0 + j] = clamp_sqrt(c);
+        }
+    };
+    if (ds.shift == 0)      // (no rotation: rows as they lie -- the form with one pointer per staged pair; it checks alignment itself)
+        gemm_nt_tile_f64_rows(sm, d, feats + (ds.x_row0 + i0) * (int64_t)d, d, ds.nx - i0, feats + (ds.y_row0 + j0) * (int64_t)d, d, ds.ny - j0, store);
+    else
+        gemm_nt_tile_f64(
+            sm, d,
+            [&](const int r, const int k) {
+                int src = k - ds.shift;                    // np.roll(chroma_i, oti) (Serra09.py:167)
+                if (src < 0) src += d;
+                return (i0 + r < ds.nx && k < d) ? feats[(ds.x_row0 + i0 + r) * d + src] : 0.0;
+            },
+            [&](const int r, const int k) { return (j0 + r < ds.ny && k < d) ? feats[(ds.y_row0 + j0 + r) * d + k] : 0.0; }, store);
 }
 
 // The same for float32 features (the reference keeps the scattering features in float32, Serra09.py:187-192, and
