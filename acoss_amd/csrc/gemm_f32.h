@@ -185,4 +185,7 @@ __device__ inline void gemm_nt_tile_f32_rows(Gemm32Smem<WM, WN> &sm, int kdim, c
             for (int r = 0; r < 4; r++) store(wi + 16 * ta + 4 * lk + r, wj + 16 * tb + lr, acc[ta][tb][r]);
 }
 
+// (Built and measured, not kept: the DMA form of gemm_f64.h for this tile -- two images of 33 KB, groups of eight rows 1040 bytes apart, one
+//  barrier per chunk, bit-identical: 9.16 ms against 8.97 for the pointer form above on the 20 736-d CSM of 28 pairs.)
+
 }  // namespace acoss
