@@ -103,6 +103,9 @@ def test_scorer_long_songs_with_exact_ties_come_round_again(lib, orc):
             os.environ["ACOSS_RADIX16"] = flag
             q, d, _ = _scores(lib, feats, off, gc, pairs, want=3)
             assert np.array_equal(q, q64) and np.array_equal(d, d64), flag
+        os.environ["ACOSS_RADIX16"] = "1"
+        q, d, _ = _scores(lib, feats, off, gc, pairs, want=3, batch_pairs=2)      # three batches, each with pairs that come round again
+        assert np.array_equal(q, q64) and np.array_equal(d, d64)
     finally:
         for k, v in old.items():
             if v is None:
